@@ -1,0 +1,229 @@
+/*
+ * tamgcn.h — C ABI of the MI355X-native CTR-GCN hot path (libtamgcn.so).
+ *
+ * The reference (Tamnemng/TAM-GCN) has no FFI / operator registry: its hot
+ * path is stock ATen ops issued from models/ctrgcn.py.  The
+ * entry points below are therefore what a binding for that path binds
+ * instead of those ATen calls; each one cites the reference lines whose
+ * arithmetic it replaces.  Plain pointers and sizes only: no torch types.
+ *
+ * Conventions
+ *   - every tensor is fp32, dense, NCHW-contiguous (N, C, T, V), V innermost,
+ *     and lives in device (HBM) memory owned by the caller;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*),
+ *     allocates nothing, never synchronises the device and is safe inside
+ *     hipGraph stream capture; scratch/partial buffers are caller-provided;
+ *   - return value 0 = launched; <0 = rejected before any launch
+ *     (tamgcn_last_error() gives the reason for the calling thread);
+ *   - calls are re-entrant per stream: no global mutable state.
+ *
+ * "src" operands.  Most kernels read their activation operand through a fused
+ * per-channel affine/mix prologue so that train-mode BatchNorm apply (forward)
+ * and BatchNorm-backward apply never cost a separate pass over HBM:
+ *      value(n,c,t,v) = act( c1[c]*x1 + c2[c]*x2 + c0[c] )
+ * with coef = [3][ctot] = (c1, c2, c0) indexed by absolute channel, x2 and
+ * coef optional (NULL: value = x1), act 0 = identity, 1 = ReLU.
+ * Out-of-range taps (temporal zero padding) are 0 *after* the prologue, as in
+ * the reference where padding follows BN+ReLU (models/ctrgcn.py:95-107).
+ */
+#ifndef TAMGCN_H
+#define TAMGCN_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TAMGCN_VERSION 100          /* 0.1.0 */
+#define TAMGCN_MAX_SUBSETS 3
+#define TAMGCN_MAX_V 32             /* joints supported by the LDS-resident CTRGC tiles */
+
+typedef struct tamgcn_src {
+    const float* x1;
+    const float* x2;                /* optional */
+    const float* coef;              /* optional, [3][ctot] */
+    int ctot;                       /* channels of the x1/x2 allocations */
+    int coff;                       /* first channel used */
+    int act;                        /* 0 none, 1 relu */
+} tamgcn_src;
+
+/* ------------------------------------------------------------------------
+ * Library
+ * --------------------------------------------------------------------- */
+int         tamgcn_version(void);
+const char* tamgcn_last_error(void);
+/* bytes of LDS the CTRGC kernels need for (S subsets, V joints, R rel-channels);
+ * <0 if the shape is unsupported.  Lets the host fail early and loudly. */
+int         tamgcn_ctrgc_lds_bytes(int S, int V, int R);
+
+/* ------------------------------------------------------------------------
+ * k x 1 convolution over (N,C,T,V) as an MFMA GEMM (fp32 in / fp32 acc,
+ * v_mfma_f32_16x16x4_f32).  Replaces aten::convolution for
+ *   - 1x1 channel mixing: CTRGC conv1..4 on pooled joints, unit_gcn.down,
+ *     unit_gcn.offset_conv, the 4 MS-TCN branch entry convs, unit_tcn
+ *     (reference models/ctrgcn.py:161-164, 211-213, 219-221, 95-99, 114, 122, 183)
+ *   - dilated temporal convs (TemporalConv, models/ctrgcn.py:56-62)
+ * and, with wmode = 1, for their data gradients (aten::convolution_backward,
+ * input part): the weight is then read transposed with taps flipped and the
+ * src is zero-upsampled by `up` (the forward stride).
+ *
+ *   y[n, ycoff+m, (t*ostride), v] = bias[m]
+ *        + sum_{k,j} W(m,k,j) * src(n, k, t*stride + j*dil - pad, v)
+ *        + bcast[m, n, v]*bcast_scale + add1[...] + add2[...]
+ *   then  y *= (mask_src > 0)  if mask is given,
+ *   and per-channel partial sums  (sum y, sum y*aux)  -> stats_part
+ *   (aux = y itself when aux is NULL: the train-mode BatchNorm moments).
+ * ---------------------------------------------------------------------- */
+typedef struct tamgcn_conv_desc {
+    tamgcn_src src;                 /* (N, src.ctot, T_in, V); uses K channels from src.coff */
+    int N, K, T_in, V;
+    const float* w;                 /* wmode 0: [M][K][KT]   wmode 1: [K][M][KT] (read transposed+flipped) */
+    const float* bias;              /* [M] or NULL */
+    int M, KT, dil, stride, pad;
+    int wmode;                      /* 0 forward, 1 data-gradient */
+    int up;                         /* src zero-upsampling factor (1 = none); wmode 1 with strided fwd */
+    float* y;                       /* (N, yctot, T_y, V) */
+    int yctot, ycoff;
+    int T_out;                      /* number of output t computed */
+    int T_y;                        /* T extent of the y allocation */
+    int ostride;                    /* output t stride (1; 2 scatters a strided 1x1 data-gradient) */
+    const float* add1;              /* optional, same geometry as y (may alias y) */
+    const float* add2;              /* optional, same geometry as y */
+    const float* bcast;             /* optional [M][N][V], broadcast over t */
+    float bcast_scale;
+    const tamgcn_src* mask;         /* optional, geometry of y: y *= (value > 0) */
+    const float* aux;               /* optional, geometry (N, auxctot, T_y, V) at auxcoff */
+    int auxctot, auxcoff;
+    float* stats_part;              /* optional [2][stats_ctot][nparts] written at channel stats_coff+m */
+    int stats_ctot, stats_coff;
+} tamgcn_conv_desc;
+
+/* number of stats partials per channel the call writes (= N * t-tiles) */
+int tamgcn_conv_nparts(const tamgcn_conv_desc* d);
+int tamgcn_conv(const tamgcn_conv_desc* d, void* stream);
+
+/* Weight gradient of the same convolution (aten::convolution_backward, weight part):
+ *   dW[m][k][j] = sum_{n,t,v} gy(n,m,t,v) * src(n,k,t*stride + j*dil - pad, v)
+ * Both operands go through the prologue.  Split over n into `nsplit` partial
+ * slabs (deterministic: no float atomics), reduced by tamgcn_reduce_sum. */
+typedef struct tamgcn_wgrad_desc {
+    tamgcn_src gy;                  /* (N, gy.ctot, T_out, V), M channels from gy.coff */
+    tamgcn_src src;                 /* (N, src.ctot, T_in, V), K channels from src.coff */
+    int N, M, K, T_in, T_out, V, KT, dil, stride, pad;
+    float* part;                    /* [nsplit][M][K][KT] */
+    int nsplit;
+} tamgcn_wgrad_desc;
+int tamgcn_wgrad(const tamgcn_wgrad_desc* d, void* stream);
+
+/* out[e] = (accumulate ? out[e] : 0) + scale * sum_{s<nsplit} part[s*stride_s + e] */
+int tamgcn_reduce_sum(const float* part, int nsplit, long long stride_s, long long count,
+                      float scale, int accumulate, float* out, void* stream);
+
+/* ------------------------------------------------------------------------
+ * BatchNorm bookkeeping (aten::native_batch_norm / _backward,
+ * reference nn.BatchNorm2d at models/ctrgcn.py:64,100,115,118,123,186,213,221,230)
+ * ---------------------------------------------------------------------- */
+/* training=1: mean/var from partial sums [2][part_ctot][nparts] (channels part_coff..+C),
+ *             running stats updated (momentum, unbiased var), *nbt += 1;
+ * training=0: running stats used.
+ * Writes coef (c1 = gamma*invstd, c2 = 0, c0 = beta - mean*c1) at channels coef_coff..+C of
+ * a [3][coef_ctot] array and save = (mean, invstd) at the same channels of a [2][coef_ctot] array. */
+int tamgcn_bn_fwd_finalize(const float* part, int part_ctot, int part_coff, int nparts, double count,
+                           const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, long long* num_batches_tracked,
+                           float momentum, float eps, int training,
+                           float* coef, float* save, int coef_ctot, int coef_coff, int C, void* stream);
+
+/* part = [2][part_ctot][nparts] partial sums of (dz, dz*x_pre) per channel.
+ * Produces dgamma, dbeta, the bias gradient of the conv that fed the BN (optional) and the
+ * backward-apply coefficients  d x_pre = c1*dz + c2*x_pre + c0  (train: full BN backward;
+ * eval: c1 = gamma*invstd, c2 = c0 = 0). */
+int tamgcn_bn_bwd_finalize(const float* part, int part_ctot, int part_coff, int nparts, double count,
+                           const float* gamma, const float* save, int save_ctot, int save_coff,
+                           int training, float* dgamma, float* dbeta, float* dbias_conv,
+                           float* coef, int coef_ctot, int coef_coff, int C, void* stream);
+
+/* ------------------------------------------------------------------------
+ * CTRGC — channel-wise topology refinement graph convolution
+ * (reference models/ctrgcn.py:172-177, and the 3-subset sum :252-254).
+ * ---------------------------------------------------------------------- */
+/* xbar[c][n][v] = mean_t src(n,c,t,v)   (layout (C, N, V): one "sample" with T = N, so the
+ * pooled 1x1 convs conv1/conv2 run through tamgcn_conv with N=1, T=N). */
+int tamgcn_tmean(const tamgcn_src* src, int N, int C, int T, int V, float* xbar, void* stream);
+
+typedef struct tamgcn_ctrgc_desc {
+    int N, Cin, Cout, S, R, T, V;
+    tamgcn_src x;                   /* block input (N, Cin, T, V) */
+    const float* pq;                /* [S*2*R][N][V]: row (s*2+0)*R+r = p, (s*2+1)*R+r = q  (conv1/conv2 of xbar) */
+    const float* w3;                /* [S*Cout][Cin]  conv3 weights, subsets stacked */
+    const float* b3;                /* [S*Cout] */
+    const float* w4;                /* [S][Cout][R]   conv4 */
+    const float* b4;                /* [S][Cout] */
+    const float* A;                 /* [S][V][V]      PA (or the A given to CTRGC.forward) */
+    const float* alpha;             /* [1] device scalar */
+} tamgcn_ctrgc_desc;
+
+/* y[n,c,t,u] = sum_s sum_v E_s[n,c,u,v] * (W3_s x + b3_s)[n,c,t,v],
+ * E_s = alpha*(W4_s tanh(p_s[u]-q_s[v]) + b4_s) + A_s ; E lives only in LDS.
+ * stats_part (optional): [2][Cout][N] partial (sum y, sum y^2) per sample. */
+int tamgcn_ctrgc_fwd(const tamgcn_ctrgc_desc* d, float* y, float* stats_part, void* stream);
+
+/* dx3[n, s*Cout+c, t, v] = sum_u E_s[n,c,u,v] * dy(n,c,t,u);  db3_part [N][S*Cout] */
+int tamgcn_ctrgc_bwd_dx3(const tamgcn_ctrgc_desc* d, const tamgcn_src* dy,
+                         float* dx3, float* db3_part, void* stream);
+
+/* dE_s[n,c,u,v] = sum_t dy(n,c,t,u) * x3_s[n,c,t,v] (x3 recomputed, never stored) pushed
+ * through E's definition:
+ *   dA_part     [N*nct][S][V][V]   (sum over the block's channels)
+ *   dw4_part    [N][S][Cout][R], db4_part [N][S][Cout], dalpha_part [N*nct]
+ *   dpq         [S*2*R][N][V]      accumulated with float atomics: zero it first
+ * nct = Cout/16 channel tiles. */
+int tamgcn_ctrgc_bwd_de(const tamgcn_ctrgc_desc* d, const tamgcn_src* dy,
+                        float* dA_part, float* dw4_part, float* db4_part, float* dalpha_part,
+                        float* dpq, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Element-wise block epilogues and their backward reductions.
+ * All stats partial buffers are [nstat][C][nparts]; nparts is returned by
+ * tamgcn_ew_nparts(N, T, V) (one partial per (n, chunk of t)).
+ * ---------------------------------------------------------------------- */
+int tamgcn_ew_nparts(int N, int C, int T, int V);
+
+/* unit_gcn tail, models/ctrgcn.py:256-261:
+ *   g = relu( ybn + tanh(obn) + res ),  ybn = y.coef-applied y_pre, obn likewise,
+ *   res = 0 | x | coef-applied d_pre  (res may be NULL). */
+int tamgcn_gcn_tail_fwd(const tamgcn_src* y, const tamgcn_src* o, const tamgcn_src* res,
+                        int N, int C, int T, int V, float* g, void* stream);
+/* dsum = dg*(g>0); doz = dsum*(1-tanh(obn)^2); partials (sum doz, sum doz*o_pre) */
+int tamgcn_gcn_tail_bwd(const float* dg, const float* g, const tamgcn_src* o,
+                        int N, int C, int T, int V, float* dsum, float* doz, float* part, void* stream);
+/* dyb = dsum - ddiff ; dres = dsum + ddiff (dres optional);
+ * part[0..1] = (sum dyb, sum dyb*y_pre); part[2..3] = (sum dres, sum dres*r_pre) if r_pre given */
+int tamgcn_gcn_mid_bwd(const float* dsum, const float* ddiff, const float* y_pre, const float* r_pre,
+                       int N, int C, int T, int V, float* dyb, float* dres, float* part, void* stream);
+
+/* MaxPool2d((3,1), stride (s,1), pad (1,0)) over the prologue value (models/ctrgcn.py:117),
+ * written at channel ycoff of y (N, yctot, T_out, V) + (sum, sum^2) partials [2][yctot][nparts]. */
+int tamgcn_maxpool_fwd(const tamgcn_src* src, int N, int C, int T_in, int V, int stride,
+                       float* y, int yctot, int ycoff, int T_out, float* stats_part, void* stream);
+/* d src_value routed to the first arg-max of each window, times relu mask (value > 0);
+ * gy goes through its own prologue; result written at channel dcoff of d (N, dctot, T_in, V),
+ * partials (sum d, sum d*src.x1) at the same channel of [2][dctot][nparts]. */
+int tamgcn_maxpool_bwd(const tamgcn_src* gy, const tamgcn_src* src, int N, int C, int T_in, int T_out, int V,
+                       int stride, float* d, int dctot, int dcoff, float* part, void* stream);
+
+/* out = act( a + res ), a = prologue value of `a`, res = NULL | src (identity or coef-applied
+ * conv residual); models/ctrgcn.py:145-146 and :283. */
+int tamgcn_add_act_fwd(const tamgcn_src* a, const tamgcn_src* res, int relu,
+                       int N, int C, int T, int V, float* out, void* stream);
+/* dz = dout * (out>0) (relu=1; dz may be NULL when relu=0 and only sums are wanted);
+ * part[0..1] = (sum dz, sum dz*a_pre), part[2..3] = (sum dz, sum dz*r_pre) if r_pre given. */
+int tamgcn_add_act_bwd(const float* dout, const float* out, int relu, const float* a_pre, const float* r_pre,
+                       int N, int C, int T, int V, float* dz, float* part, void* stream);
+
+/* y = prologue value (materialise a src; used by stand-alone modules and tests) */
+int tamgcn_apply(const tamgcn_src* src, int N, int C, int T, int V, float* y, int yctot, int ycoff, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TAMGCN_H */

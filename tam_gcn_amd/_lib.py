@@ -1,0 +1,109 @@
+"""ctypes binding of libtamgcn.so (the C ABI declared in include/tamgcn.h).
+
+The product path has no CPU fallback: if the shared object is missing or does
+not export the ABI, importing the op layer raises (fail loudly).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libtamgcn.so')
+
+c_float_p = C.c_void_p          # device pointers travel as integers
+
+
+class Src(C.Structure):
+    _fields_ = [('x1', C.c_void_p), ('x2', C.c_void_p), ('coef', C.c_void_p),
+                ('ctot', C.c_int), ('coff', C.c_int), ('act', C.c_int)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [('src', Src),
+                ('N', C.c_int), ('K', C.c_int), ('T_in', C.c_int), ('V', C.c_int),
+                ('w', C.c_void_p), ('bias', C.c_void_p),
+                ('M', C.c_int), ('KT', C.c_int), ('dil', C.c_int), ('stride', C.c_int), ('pad', C.c_int),
+                ('wmode', C.c_int), ('up', C.c_int),
+                ('y', C.c_void_p), ('yctot', C.c_int), ('ycoff', C.c_int),
+                ('T_out', C.c_int), ('T_y', C.c_int), ('ostride', C.c_int),
+                ('add1', C.c_void_p), ('add2', C.c_void_p), ('bcast', C.c_void_p), ('bcast_scale', C.c_float),
+                ('mask', C.POINTER(Src)),
+                ('aux', C.c_void_p), ('auxctot', C.c_int), ('auxcoff', C.c_int),
+                ('stats_part', C.c_void_p), ('stats_ctot', C.c_int), ('stats_coff', C.c_int)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [('gy', Src), ('src', Src),
+                ('N', C.c_int), ('M', C.c_int), ('K', C.c_int), ('T_in', C.c_int), ('T_out', C.c_int),
+                ('V', C.c_int), ('KT', C.c_int), ('dil', C.c_int), ('stride', C.c_int), ('pad', C.c_int),
+                ('part', C.c_void_p), ('nsplit', C.c_int)]
+
+
+class CtrgcDesc(C.Structure):
+    _fields_ = [('N', C.c_int), ('Cin', C.c_int), ('Cout', C.c_int), ('S', C.c_int), ('R', C.c_int),
+                ('T', C.c_int), ('V', C.c_int),
+                ('x', Src),
+                ('pq', C.c_void_p), ('w3', C.c_void_p), ('b3', C.c_void_p), ('w4', C.c_void_p),
+                ('b4', C.c_void_p), ('A', C.c_void_p), ('alpha', C.c_void_p)]
+
+
+# name -> (restype, argtypes); must list every symbol of include/tamgcn.h
+_i, _p, _d, _f, _ll = C.c_int, C.c_void_p, C.c_double, C.c_float, C.c_longlong
+_SP = C.POINTER(Src)
+SIGNATURES = {
+    'tamgcn_version': (_i, []),
+    'tamgcn_last_error': (C.c_char_p, []),
+    'tamgcn_ctrgc_lds_bytes': (_i, [_i, _i, _i]),
+    'tamgcn_conv_nparts': (_i, [C.POINTER(ConvDesc)]),
+    'tamgcn_conv': (_i, [C.POINTER(ConvDesc), _p]),
+    'tamgcn_wgrad': (_i, [C.POINTER(WgradDesc), _p]),
+    'tamgcn_reduce_sum': (_i, [_p, _i, _ll, _ll, _f, _i, _p, _p]),
+    'tamgcn_bn_fwd_finalize': (_i, [_p, _i, _i, _i, _d, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _i, _i, _i, _p]),
+    'tamgcn_bn_bwd_finalize': (_i, [_p, _i, _i, _i, _d, _p, _p, _i, _i, _i, _p, _p, _p, _p, _i, _i, _i, _p]),
+    'tamgcn_tmean': (_i, [_SP, _i, _i, _i, _i, _p, _p]),
+    'tamgcn_ctrgc_fwd': (_i, [C.POINTER(CtrgcDesc), _p, _p, _p]),
+    'tamgcn_ctrgc_bwd_dx3': (_i, [C.POINTER(CtrgcDesc), _SP, _p, _p, _p]),
+    'tamgcn_ctrgc_bwd_de': (_i, [C.POINTER(CtrgcDesc), _SP, _p, _p, _p, _p, _p, _p]),
+    'tamgcn_ew_nparts': (_i, [_i, _i, _i, _i]),
+    'tamgcn_gcn_tail_fwd': (_i, [_SP, _SP, _SP, _i, _i, _i, _i, _p, _p]),
+    'tamgcn_gcn_tail_bwd': (_i, [_p, _p, _SP, _i, _i, _i, _i, _p, _p, _p, _p]),
+    'tamgcn_gcn_mid_bwd': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
+    'tamgcn_maxpool_fwd': (_i, [_SP, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _p]),
+    'tamgcn_maxpool_bwd': (_i, [_SP, _SP, _i, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p]),
+    'tamgcn_add_act_fwd': (_i, [_SP, _SP, _i, _i, _i, _i, _i, _p, _p]),
+    'tamgcn_add_act_bwd': (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
+    'tamgcn_apply': (_i, [_SP, _i, _i, _i, _i, _p, _i, _i, _p]),
+}
+
+
+class TamgcnLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libtamgcn.so and bind every ABI symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TamgcnLibraryError(
+            f'{LIB_PATH} not found: the HIP extension is not built.  Run '
+            '`python -m tam_gcn_amd.build` (needs hipcc, gfx950).  There is no CPU fallback.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise TamgcnLibraryError(f'{LIB_PATH} does not export {name}') from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().tamgcn_last_error()
+        raise RuntimeError(f'{what} failed ({rc}): {msg.decode(errors="replace") if msg else "?"}')

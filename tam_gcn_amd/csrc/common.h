@@ -1,0 +1,88 @@
+// Shared device/host helpers for libtamgcn (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/tamgcn.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------
+// host side: error reporting
+// ---------------------------------------------------------------------------
+void tamgcn_set_error(const char* fmt, ...);
+
+#define TG_CHECK(cond, ...)                         \
+    do {                                            \
+        if (!(cond)) {                              \
+            tamgcn_set_error(__VA_ARGS__);          \
+            return -1;                              \
+        }                                           \
+    } while (0)
+
+#define TG_LAUNCH_CHECK(name)                                                         \
+    do {                                                                              \
+        hipError_t e_ = hipGetLastError();                                            \
+        if (e_ != hipSuccess) {                                                       \
+            tamgcn_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));   \
+            return -2;                                                                \
+        }                                                                             \
+    } while (0)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------
+// device side: fused operand prologue  value = act(c1*x1 + c2*x2 + c0)
+// ---------------------------------------------------------------------------
+struct SrcDev {
+    const float* x1;
+    const float* x2;
+    const float* coef;   // [3][ctot] or null
+    int ctot, coff, act;
+};
+
+static inline SrcDev make_src(const tamgcn_src& s) {
+    SrcDev d;
+    d.x1 = s.x1; d.x2 = s.x2; d.coef = s.coef; d.ctot = s.ctot; d.coff = s.coff; d.act = s.act;
+    return d;
+}
+static inline SrcDev null_src() {
+    SrcDev d; d.x1 = nullptr; d.x2 = nullptr; d.coef = nullptr; d.ctot = 0; d.coff = 0; d.act = 0;
+    return d;
+}
+
+// idx = element offset inside the (N, ctot, T, V) allocation, ch = absolute channel
+__device__ __forceinline__ float src_value(const SrcDev& s, long long idx, int ch) {
+    float v = s.x1[idx];
+    if (s.coef) {
+        float c1 = s.coef[ch], c0 = s.coef[2 * s.ctot + ch];
+        v = fmaf(c1, v, c0);
+        if (s.x2) v = fmaf(s.coef[s.ctot + ch], s.x2[idx], v);
+    }
+    if (s.act == 1) v = fmaxf(v, 0.f);
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum16(float v) {   // sum over the 16 lanes sharing lane>>4
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    return v;
+}
+__device__ __forceinline__ float wave_sum64(float v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+// v_mfma_f32_16x16x4_f32: A[i=lane&15][k=lane>>4], B[k=lane>>4][j=lane&15],
+// D[row = 4*(lane>>4) + reg][col = lane&15]   (cdna_hip_programming.md §3)
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}

@@ -1,0 +1,267 @@
+// HBM-bound element-wise epilogues of the CTR-GCN block and the per-channel
+// reductions their backward needs.  One workgroup streams one (n, c) row of
+// T*V contiguous floats (coalesced along t*V+v); per-channel partial sums go
+// to [stat][C][N] slabs (deterministic, finalised in fp64 by bn.hip).
+// Reference: models/ctrgcn.py:117 (max-pool), :145-146, :256-261, :283.
+#include "common.h"
+
+namespace {
+
+constexpr int EW_THREADS = 256;
+
+__device__ __forceinline__ void block_store_sums(const float* vals, int nst, float* part, int C, int N, int c, int n) {
+    __shared__ float red[8][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int s = 0; s < nst; ++s) {
+        float v = wave_sum64(vals[s]);
+        if (lane == 0) red[s][wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < nst) {
+        int s = threadIdx.x;
+        part[((long long)s * C + c) * N + n] = red[s][0] + red[s][1] + red[s][2] + red[s][3];
+    }
+}
+
+// ---- unit_gcn tail -------------------------------------------------------
+__global__ __launch_bounds__(EW_THREADS) void gcn_tail_fwd_kernel(SrcDev y, SrcDev o, SrcDev res, int has_res,
+                                                                  int C, int L, float* g) {
+    const int c = blockIdx.x, n = blockIdx.y;
+    const long long by = ((long long)n * y.ctot + y.coff + c) * L;
+    const long long bo = ((long long)n * o.ctot + o.coff + c) * L;
+    const long long br = has_res ? ((long long)n * res.ctot + res.coff + c) * L : 0;
+    float* gp = g + ((long long)n * C + c) * L;
+    for (int i = threadIdx.x; i < L; i += EW_THREADS) {
+        float v = src_value(y, by + i, y.coff + c) + tanhf(src_value(o, bo + i, o.coff + c));
+        if (has_res) v += src_value(res, br + i, res.coff + c);
+        gp[i] = fmaxf(v, 0.f);
+    }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void gcn_tail_bwd_kernel(const float* dg, const float* g, SrcDev o,
+                                                                  int C, int L, int N, float* dsum, float* doz, float* part) {
+    const int c = blockIdx.x, n = blockIdx.y;
+    const long long b = ((long long)n * C + c) * L;
+    const long long bo = ((long long)n * o.ctot + o.coff + c) * L;
+    float s[2] = {0.f, 0.f};
+    for (int i = threadIdx.x; i < L; i += EW_THREADS) {
+        float d = g[b + i] > 0.f ? dg[b + i] : 0.f;
+        float off = tanhf(src_value(o, bo + i, o.coff + c));
+        float dz = d * (1.f - off * off);
+        dsum[b + i] = d;
+        doz[b + i] = dz;
+        s[0] += dz;
+        s[1] = fmaf(dz, o.x1[bo + i], s[1]);
+    }
+    block_store_sums(s, 2, part, C, N, c, n);
+}
+
+__global__ __launch_bounds__(EW_THREADS) void gcn_mid_bwd_kernel(const float* dsum, const float* ddiff, const float* y_pre,
+                                                                 const float* r_pre, int C, int L, int N,
+                                                                 float* dyb, float* dres, float* part) {
+    const int c = blockIdx.x, n = blockIdx.y;
+    const long long b = ((long long)n * C + c) * L;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < L; i += EW_THREADS) {
+        float d = dsum[b + i], dd = ddiff[b + i];
+        float a = d - dd, r = d + dd;
+        dyb[b + i] = a;
+        s[0] += a;
+        s[1] = fmaf(a, y_pre[b + i], s[1]);
+        if (dres) dres[b + i] = r;
+        if (r_pre) { s[2] += r; s[3] = fmaf(r, r_pre[b + i], s[3]); }
+    }
+    block_store_sums(s, r_pre ? 4 : 2, part, C, N, c, n);
+}
+
+// ---- max-pool branch ------------------------------------------------------
+__global__ __launch_bounds__(EW_THREADS) void maxpool_fwd_kernel(SrcDev src, int C, int T_in, int V, int stride,
+                                                                 float* y, int yctot, int ycoff, int T_out, int N, float* part) {
+    const int c = blockIdx.x, n = blockIdx.y;
+    const long long bs = ((long long)n * src.ctot + src.coff + c) * T_in * V;
+    float* yp = y + ((long long)n * yctot + ycoff + c) * T_out * V;
+    float s[2] = {0.f, 0.f};
+    for (int i = threadIdx.x; i < T_out * V; i += EW_THREADS) {
+        int t = i / V, v = i - t * V;
+        float best = -INFINITY;
+        for (int k = -1; k <= 1; ++k) {
+            int th = t * stride + k;
+            if (th >= 0 && th < T_in) best = fmaxf(best, src_value(src, bs + (long long)th * V + v, src.coff + c));
+        }
+        yp[i] = best;
+        s[0] += best;
+        s[1] = fmaf(best, best, s[1]);
+    }
+    if (part) block_store_sums(s, 2, part, yctot, N, ycoff + c, n);
+}
+
+__global__ __launch_bounds__(EW_THREADS) void maxpool_bwd_kernel(SrcDev gy, SrcDev src, int C, int T_in, int T_out, int V,
+                                                                 int stride, float* d, int dctot, int dcoff, int N, float* part) {
+    const int c = blockIdx.x, n = blockIdx.y;
+    const long long bs = ((long long)n * src.ctot + src.coff + c) * T_in * V;
+    const long long bg = ((long long)n * gy.ctot + gy.coff + c) * T_out * V;
+    float* dp = d + ((long long)n * dctot + dcoff + c) * T_in * V;
+    float s[2] = {0.f, 0.f};
+    for (int i = threadIdx.x; i < T_in * V; i += EW_THREADS) {
+        int th = i / V, v = i - th * V;
+        float x0 = src_value(src, bs + i, src.coff + c);
+        float grad = 0.f;
+        if (x0 > 0.f) {
+            // windows t with |t*stride - th| <= 1
+            int lo = th - 1; lo = lo < 0 ? 0 : (lo + stride - 1) / stride;
+            int hi = (th + 1) / stride; if (hi > T_out - 1) hi = T_out - 1;
+            for (int t = lo; t <= hi; ++t) {
+                // first arg-max of the window (aten max_pool2d keeps the first maximal index)
+                int arg = -1; float best = -INFINITY;
+                for (int k = -1; k <= 1; ++k) {
+                    int tt = t * stride + k;
+                    if (tt < 0 || tt >= T_in) continue;
+                    float xv = (tt == th) ? x0 : src_value(src, bs + (long long)tt * V + v, src.coff + c);
+                    if (xv > best) { best = xv; arg = tt; }
+                }
+                if (arg == th) grad += src_value(gy, bg + (long long)t * V + v, gy.coff + c);
+            }
+        }
+        dp[i] = grad;
+        s[0] += grad;
+        s[1] = fmaf(grad, src.x1[bs + i], s[1]);
+    }
+    if (part) block_store_sums(s, 2, part, dctot, N, dcoff + c, n);
+}
+
+// ---- residual add (+ReLU) -------------------------------------------------
+__global__ __launch_bounds__(EW_THREADS) void add_act_fwd_kernel(SrcDev a, SrcDev res, int has_res, int relu,
+                                                                 int C, int L, float* out) {
+    const int c = blockIdx.x, n = blockIdx.y;
+    const long long ba = ((long long)n * a.ctot + a.coff + c) * L;
+    const long long br = has_res ? ((long long)n * res.ctot + res.coff + c) * L : 0;
+    float* op = out + ((long long)n * C + c) * L;
+    for (int i = threadIdx.x; i < L; i += EW_THREADS) {
+        float v = src_value(a, ba + i, a.coff + c);
+        if (has_res) v += src_value(res, br + i, res.coff + c);
+        op[i] = relu ? fmaxf(v, 0.f) : v;
+    }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void add_act_bwd_kernel(const float* dout, const float* out, int relu,
+                                                                 const float* a_pre, const float* r_pre,
+                                                                 int C, int L, int N, float* dz, float* part) {
+    const int c = blockIdx.x, n = blockIdx.y;
+    const long long b = ((long long)n * C + c) * L;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < L; i += EW_THREADS) {
+        float d = dout[b + i];
+        if (relu && !(out[b + i] > 0.f)) d = 0.f;
+        if (dz) dz[b + i] = d;
+        s[0] += d;
+        if (a_pre) s[1] = fmaf(d, a_pre[b + i], s[1]);
+        if (r_pre) { s[2] += d; s[3] = fmaf(d, r_pre[b + i], s[3]); }
+    }
+    block_store_sums(s, r_pre ? 4 : 2, part, C, N, c, n);
+}
+
+__global__ __launch_bounds__(EW_THREADS) void apply_kernel(SrcDev src, int L, float* y, int yctot, int ycoff) {
+    const int c = blockIdx.x, n = blockIdx.y;
+    const long long bs = ((long long)n * src.ctot + src.coff + c) * L;
+    float* yp = y + ((long long)n * yctot + ycoff + c) * L;
+    for (int i = threadIdx.x; i < L; i += EW_THREADS) yp[i] = src_value(src, bs + i, src.coff + c);
+}
+
+// xbar[c][n][v] = mean_t value(n,c,t,v)
+__global__ __launch_bounds__(EW_THREADS) void tmean_kernel(SrcDev src, int N, int C, int T, int V, float* xbar) {
+    const int cpb = EW_THREADS / V;                   // channels per block
+    const int cl = threadIdx.x / V, v = threadIdx.x - cl * V;
+    const int c = blockIdx.x * cpb + cl, n = blockIdx.y;
+    if (cl >= cpb || c >= C) return;
+    const long long b = ((long long)n * src.ctot + src.coff + c) * T * V + v;
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += src_value(src, b + (long long)t * V, src.coff + c);
+    xbar[((long long)c * N + n) * V + v] = s / (float)T;
+}
+
+static bool grid_ok(int N, int C) { return N > 0 && C > 0 && N <= 65535; }
+
+}  // namespace
+
+extern "C" int tamgcn_ew_nparts(int N, int C, int T, int V) { (void)C; (void)T; (void)V; return N; }
+
+extern "C" int tamgcn_gcn_tail_fwd(const tamgcn_src* y, const tamgcn_src* o, const tamgcn_src* res,
+                                   int N, int C, int T, int V, float* g, void* stream) {
+    TG_CHECK(y && o && g && y->x1 && o->x1 && grid_ok(N, C), "tamgcn_gcn_tail_fwd: bad args");
+    hipLaunchKernelGGL(gcn_tail_fwd_kernel, dim3(C, N), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       make_src(*y), make_src(*o), res ? make_src(*res) : null_src(), res ? 1 : 0, C, T * V, g);
+    TG_LAUNCH_CHECK("tamgcn_gcn_tail_fwd");
+    return 0;
+}
+
+extern "C" int tamgcn_gcn_tail_bwd(const float* dg, const float* g, const tamgcn_src* o,
+                                   int N, int C, int T, int V, float* dsum, float* doz, float* part, void* stream) {
+    TG_CHECK(dg && g && o && o->x1 && dsum && doz && part && grid_ok(N, C), "tamgcn_gcn_tail_bwd: bad args");
+    hipLaunchKernelGGL(gcn_tail_bwd_kernel, dim3(C, N), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       dg, g, make_src(*o), C, T * V, N, dsum, doz, part);
+    TG_LAUNCH_CHECK("tamgcn_gcn_tail_bwd");
+    return 0;
+}
+
+extern "C" int tamgcn_gcn_mid_bwd(const float* dsum, const float* ddiff, const float* y_pre, const float* r_pre,
+                                  int N, int C, int T, int V, float* dyb, float* dres, float* part, void* stream) {
+    TG_CHECK(dsum && ddiff && y_pre && dyb && part && grid_ok(N, C), "tamgcn_gcn_mid_bwd: bad args");
+    hipLaunchKernelGGL(gcn_mid_bwd_kernel, dim3(C, N), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       dsum, ddiff, y_pre, r_pre, C, T * V, N, dyb, dres, part);
+    TG_LAUNCH_CHECK("tamgcn_gcn_mid_bwd");
+    return 0;
+}
+
+extern "C" int tamgcn_maxpool_fwd(const tamgcn_src* src, int N, int C, int T_in, int V, int stride,
+                                  float* y, int yctot, int ycoff, int T_out, float* stats_part, void* stream) {
+    TG_CHECK(src && src->x1 && y && grid_ok(N, C) && stride >= 1, "tamgcn_maxpool_fwd: bad args");
+    TG_CHECK(T_out == (T_in + 2 - 3) / stride + 1, "tamgcn_maxpool_fwd: T_out=%d inconsistent with T_in=%d stride=%d", T_out, T_in, stride);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(C, N), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       make_src(*src), C, T_in, V, stride, y, yctot, ycoff, T_out, N, stats_part);
+    TG_LAUNCH_CHECK("tamgcn_maxpool_fwd");
+    return 0;
+}
+
+extern "C" int tamgcn_maxpool_bwd(const tamgcn_src* gy, const tamgcn_src* src, int N, int C, int T_in, int T_out, int V,
+                                  int stride, float* d, int dctot, int dcoff, float* part, void* stream) {
+    TG_CHECK(gy && src && gy->x1 && src->x1 && d && grid_ok(N, C) && stride >= 1, "tamgcn_maxpool_bwd: bad args");
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(C, N), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       make_src(*gy), make_src(*src), C, T_in, T_out, V, stride, d, dctot, dcoff, N, part);
+    TG_LAUNCH_CHECK("tamgcn_maxpool_bwd");
+    return 0;
+}
+
+extern "C" int tamgcn_add_act_fwd(const tamgcn_src* a, const tamgcn_src* res, int relu,
+                                  int N, int C, int T, int V, float* out, void* stream) {
+    TG_CHECK(a && a->x1 && out && grid_ok(N, C), "tamgcn_add_act_fwd: bad args");
+    hipLaunchKernelGGL(add_act_fwd_kernel, dim3(C, N), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       make_src(*a), res ? make_src(*res) : null_src(), res ? 1 : 0, relu, C, T * V, out);
+    TG_LAUNCH_CHECK("tamgcn_add_act_fwd");
+    return 0;
+}
+
+extern "C" int tamgcn_add_act_bwd(const float* dout, const float* out, int relu, const float* a_pre, const float* r_pre,
+                                  int N, int C, int T, int V, float* dz, float* part, void* stream) {
+    TG_CHECK(dout && part && grid_ok(N, C) && (!relu || out), "tamgcn_add_act_bwd: bad args");
+    hipLaunchKernelGGL(add_act_bwd_kernel, dim3(C, N), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       dout, out, relu, a_pre, r_pre, C, T * V, N, dz, part);
+    TG_LAUNCH_CHECK("tamgcn_add_act_bwd");
+    return 0;
+}
+
+extern "C" int tamgcn_apply(const tamgcn_src* src, int N, int C, int T, int V, float* y, int yctot, int ycoff, void* stream) {
+    TG_CHECK(src && src->x1 && y && grid_ok(N, C), "tamgcn_apply: bad args");
+    hipLaunchKernelGGL(apply_kernel, dim3(C, N), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       make_src(*src), T * V, y, yctot, ycoff);
+    TG_LAUNCH_CHECK("tamgcn_apply");
+    return 0;
+}
+
+extern "C" int tamgcn_tmean(const tamgcn_src* src, int N, int C, int T, int V, float* xbar, void* stream) {
+    TG_CHECK(src && src->x1 && xbar && grid_ok(N, C) && V <= EW_THREADS, "tamgcn_tmean: bad args");
+    int cpb = EW_THREADS / V;
+    hipLaunchKernelGGL(tmean_kernel, dim3(ceil_div(C, cpb), N), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       make_src(*src), N, C, T, V, xbar);
+    TG_LAUNCH_CHECK("tamgcn_tmean");
+    return 0;
+}

@@ -1,0 +1,438 @@
+"""Forward/backward orchestration of the HIP ops for the CTR-GCN block, and the
+autograd.Function wrappers the nn.Module mirror (models/ctrgcn.py) calls.
+
+Everything numeric happens in libtamgcn.so; this file only sequences kernels,
+allocates outputs and routes gradients to parameters.  Train-mode BatchNorm is
+split as  producer(+moment partials) -> bn_*_finalize -> consumer(prologue).
+
+Reference arithmetic being reproduced: models/ctrgcn.py:52-69 (TemporalConv),
+:72-147 (MultiScale_TemporalConv), :150-177 (CTRGC), :179-193 (unit_tcn),
+:196-263 (unit_gcn), :266-284 (TCN_GCN_unit).
+"""
+import torch
+
+from . import ops
+from .ops import S, RELU
+
+
+class BN:
+    """Borrowed view of one nn.BatchNorm{1,2}d's tensors."""
+    __slots__ = ('w', 'b', 'rm', 'rv', 'nbt', 'mom', 'eps', 'C')
+
+    def __init__(self, m):
+        if m.momentum is None or not m.track_running_stats or not m.affine:
+            raise RuntimeError('tam_gcn_amd: BatchNorm must be affine with running stats and a fixed momentum')
+        self.w, self.b, self.rm, self.rv, self.nbt = m.weight, m.bias, m.running_mean, m.running_var, m.num_batches_tracked
+        self.mom, self.eps, self.C = float(m.momentum), float(m.eps), m.num_features
+
+    def fwd(self, part, part_coff, count, training, coef, save, coff):
+        ops.bn_fwd_finalize(part, part_coff, count, self.w, self.b, self.rm, self.rv, self.nbt, self.mom, self.eps,
+                            training, coef, save, coff, self.C)
+
+    def bwd(self, part, part_coff, count, save, save_coff, training, coef, coff, want_dbias=False):
+        dev = self.w.device
+        dg = torch.empty(self.C, device=dev)
+        db = torch.empty(self.C, device=dev)
+        dbias = torch.empty(self.C, device=dev) if want_dbias else None
+        ops.bn_bwd_finalize(part, part_coff, count, self.w, save, save_coff, training, dg, db, dbias, coef, coff, self.C)
+        return dg, db, dbias
+
+
+def _coef(C_, like):
+    return torch.empty(3, C_, device=like.device), torch.empty(2, C_, device=like.device)
+
+
+# ===========================================================================
+# unit_gcn
+# ===========================================================================
+class GcnParams:
+    """Tensors of one unit_gcn, with the per-subset conv weights stacked."""
+    __slots__ = ('S', 'R', 'Cin', 'Cout', 'PA', 'alpha', 'W12', 'B12', 'W3', 'B3', 'W4', 'B4',
+                 'bn', 'mode', 'Wd', 'bd', 'bnd', 'Wo', 'bo', 'bno')
+
+
+def gcn_forward(x, P, training, save):
+    N, Cin, T, V = x.shape
+    S_, R, Cout = P.S, P.R, P.Cout
+    count = N * T * V
+    xs = S(x)
+    # pooled joint embeddings (conv1/conv2 commute with the mean over T)
+    xbar = ops.tmean(xs, Cin)                                             # (Cin, N, V)
+    pq, _ = ops.conv(S(xbar.view(1, Cin, N, V)), K=Cin, w=P.W12, bias=P.B12, M=S_ * 2 * R)
+    pq = pq.view(S_ * 2 * R, N, V)
+    y_pre, ypart = ops.ctrgc_fwd(xs, pq, P.W3, P.B3, P.W4, P.B4, P.PA, P.alpha, Cin, Cout, S_, R, stats=training)
+    coef_y, save_y = _coef(Cout, x)
+    P.bn.fwd(ypart, 0, count, training, coef_y, save_y, 0)
+    d_pre = coef_d = save_d = None
+    if P.mode == 'conv':
+        d_pre, dpart = ops.conv(xs, K=Cin, w=P.Wd, bias=P.bd, M=Cout, stats=training)
+        coef_d, save_d = _coef(Cout, x)
+        P.bnd.fwd(dpart, 0, count, training, coef_d, save_d, 0)
+        res = S(d_pre, coef=coef_d)
+        coef_diff = torch.stack((coef_d[0], -coef_y[0], coef_d[2] - coef_y[2]))
+        diff = S(d_pre, y_pre, coef_diff)
+    elif P.mode == 'identity':
+        res = xs
+        coef_diff = torch.stack((torch.ones_like(coef_y[0]), -coef_y[0], -coef_y[2]))
+        diff = S(x, y_pre, coef_diff)
+    else:                                                                  # residual=False: down(x) = 0
+        res = None
+        coef_diff = torch.stack((-coef_y[0], torch.zeros_like(coef_y[0]), -coef_y[2]))
+        diff = S(y_pre, None, coef_diff)
+    o_pre, opart = ops.conv(diff, K=Cout, w=P.Wo, bias=P.bo, M=Cout, stats=training)
+    coef_o, save_o = _coef(Cout, x)
+    P.bno.fwd(opart, 0, count, training, coef_o, save_o, 0)
+    g = ops.gcn_tail_fwd(S(y_pre, coef=coef_y), S(o_pre, coef=coef_o), res)
+    sv = None
+    if save:
+        sv = dict(x=x, xbar=xbar, pq=pq, y_pre=y_pre, d_pre=d_pre, o_pre=o_pre, g=g, coef_y=coef_y, save_y=save_y,
+                  coef_d=coef_d, save_d=save_d, coef_o=coef_o, save_o=save_o, coef_diff=coef_diff,
+                  training=training)
+    return g, sv
+
+
+def gcn_backward(P, sv, dg, need_dx=True, extra_dx=None):
+    """Returns (dx, grads) with grads keyed like GcnParams' tensors."""
+    x, xbar, pq, y_pre, d_pre, o_pre, g = sv['x'], sv['xbar'], sv['pq'], sv['y_pre'], sv['d_pre'], sv['o_pre'], sv['g']
+    training = sv['training']
+    N, Cin, T, V = x.shape
+    S_, R, Cout = P.S, P.R, P.Cout
+    count = N * T * V
+    G = {}
+    # tail: relu, tanh(BN(offset conv))
+    dsum, doz, part_o = ops.gcn_tail_bwd(dg, g, S(o_pre, coef=sv['coef_o']))
+    coefb_o = torch.empty(3, Cout, device=x.device)
+    G['bno.w'], G['bno.b'], G['bo'] = P.bno.bwd(part_o, 0, count, sv['save_o'], 0, training, coefb_o, 0, want_dbias=True)
+    gyo = S(doz, o_pre, coefb_o)
+    ddiff, _ = ops.conv(gyo, K=Cout, w=P.Wo, bias=None, M=Cout, wmode=1)
+    if P.mode == 'conv':
+        diff = S(d_pre, y_pre, sv['coef_diff'])
+    elif P.mode == 'identity':
+        diff = S(x, y_pre, sv['coef_diff'])
+    else:
+        diff = S(y_pre, None, sv['coef_diff'])
+    G['Wo'] = ops.wgrad(gyo, diff, M=Cout, K=Cout)
+    dyb, dres, part2 = ops.gcn_mid_bwd(dsum, ddiff, y_pre, d_pre if P.mode == 'conv' else None,
+                                       want_dres=P.mode != 'zero')
+    coefb_y = torch.empty(3, Cout, device=x.device)
+    G['bn.w'], G['bn.b'], _ = P.bn.bwd(part2, 0, count, sv['save_y'], 0, training, coefb_y, 0)
+    dy = S(dyb, y_pre, coefb_y)
+    # CTRGC
+    xs = S(x)
+    dx3, G['B3'], G['PA'], G['W4'], G['B4'], G['alpha'], dpq = ops.ctrgc_bwd(
+        xs, pq, P.W3, P.B3, P.W4, P.B4, P.PA, P.alpha, Cin, Cout, S_, R, dy)
+    dpq4 = S(dpq.view(1, S_ * 2 * R, N, V))
+    G['W12'] = ops.wgrad(dpq4, S(xbar.view(1, Cin, N, V)), M=S_ * 2 * R, K=Cin)
+    G['B12'] = dpq.sum((1, 2))
+    G['W3'] = ops.wgrad(S(dx3), xs, M=S_ * Cout, K=Cin)
+    dx = None
+    if need_dx:
+        dxbar, _ = ops.conv(dpq4, K=S_ * 2 * R, w=P.W12, bias=None, M=Cin, wmode=1)        # (1, Cin, N, V)
+        dx, _ = ops.conv(S(dx3), K=S_ * Cout, w=P.W3, bias=None, M=Cin, wmode=1,
+                         bcast=dxbar.view(Cin, N, V), bcast_scale=1.0 / T,
+                         add1=dres if P.mode == 'identity' else None, add2=extra_dx)
+    if P.mode == 'conv':
+        coefb_d = torch.empty(3, Cout, device=x.device)
+        G['bnd.w'], G['bnd.b'], G['bd'] = P.bnd.bwd(part2[2:4], 0, count, sv['save_d'], 0, training, coefb_d, 0,
+                                                     want_dbias=True)
+        gyd = S(dres, d_pre, coefb_d)
+        if need_dx:
+            ops.conv(gyd, K=Cout, w=P.Wd, bias=None, M=Cin, wmode=1, add1=dx, y=dx)
+        G['Wd'] = ops.wgrad(gyd, xs, M=Cout, K=Cin)
+    return dx, G
+
+
+# ===========================================================================
+# MultiScale_TemporalConv (+ optional residual and final ReLU of TCN_GCN_unit)
+# ===========================================================================
+class TcnParams:
+    """nb dilated branches + max-pool branch + plain 1x1 branch.
+    Win/bin: entry 1x1 convs of branches 0..nb stacked [(nb+1)*Cb, Cin];
+    bn_in[b], Wt[b]/bt[b]/bn_t[b] (b < nb), bn_pool, Wl/bl/bn_l (last branch);
+    residual: mode 'zero' | 'identity' | 'conv' with Wr/br/bnr, rk (kernel size)."""
+    __slots__ = ('Cin', 'Cout', 'Cb', 'nb', 'ks', 'dils', 'stride', 'Win', 'bin', 'bn_in', 'Wt', 'bt', 'bn_t',
+                 'bn_pool', 'Wl', 'bl', 'bn_l', 'rmode', 'Wr', 'br', 'bnr', 'rk', 'relu')
+
+
+def _tpad(k, d):
+    return (k + (k - 1) * (d - 1) - 1) // 2
+
+
+def tcn_forward(g, P, training, save, xres=None):
+    """g (N,Cin,T,V) -> (N,Cout,T2,V).  xres: tensor the residual branch reads
+    (defaults to g, as in MultiScale_TemporalConv; TCN_GCN_unit passes the block input)."""
+    N, Cin, T, V = g.shape
+    Cb, nb, s = P.Cb, P.nb, P.stride
+    Cout = P.Cout
+    T2 = (T - 1) // s + 1
+    cnt1, cnt2 = N * T * V, N * T2 * V
+    gs = S(g)
+    Ch = (nb + 1) * Cb
+    h_pre, hpart = ops.conv(gs, K=Cin, w=P.Win, bias=P.bin, M=Ch, stats=training)
+    coef_h, save_h = _coef(Ch, g)
+    for b in range(nb + 1):
+        P.bn_in[b].fwd(hpart, b * Cb, cnt1, training, coef_h, save_h, b * Cb)
+    cat_pre = torch.empty(N, Cout, T2, V, device=g.device)
+    coef_c, save_c = _coef(Cout, g)
+    for b in range(nb):
+        k, d = P.ks[b], P.dils[b]
+        _, part = ops.conv(S(h_pre, coef=coef_h, coff=b * Cb, act=RELU), K=Cb, w=P.Wt[b], bias=P.bt[b], M=Cb,
+                           KT=k, dil=d, stride=s, pad=_tpad(k, d), y=cat_pre, ycoff=b * Cb, T_out=T2, stats=training)
+        P.bn_t[b].fwd(part, b * Cb, cnt2, training, coef_c, save_c, b * Cb)
+    part = ops.maxpool_fwd(S(h_pre, coef=coef_h, coff=nb * Cb, act=RELU), Cb, s, cat_pre, nb * Cb, stats=training)
+    P.bn_pool.fwd(part, nb * Cb, cnt2, training, coef_c, save_c, nb * Cb)
+    _, part = ops.conv(gs, K=Cin, w=P.Wl, bias=P.bl, M=Cb, stride=s, y=cat_pre, ycoff=(nb + 1) * Cb, T_out=T2,
+                       stats=training)
+    P.bn_l.fwd(part, (nb + 1) * Cb, cnt2, training, coef_c, save_c, (nb + 1) * Cb)
+    r_pre = coef_r = save_r = None
+    if xres is None:
+        xres = g
+    if P.rmode == 'identity':
+        res = S(xres)
+    elif P.rmode == 'conv':
+        rk = P.rk
+        r_pre, rpart = ops.conv(S(xres), K=xres.shape[1], w=P.Wr, bias=P.br, M=Cout, KT=rk, stride=s,
+                                pad=(rk - 1) // 2, T_out=T2, stats=training)
+        coef_r, save_r = _coef(Cout, g)
+        P.bnr.fwd(rpart, 0, cnt2, training, coef_r, save_r, 0)
+        res = S(r_pre, coef=coef_r)
+    else:
+        res = None
+    out = ops.add_act_fwd(S(cat_pre, coef=coef_c), res, P.relu, Cout)
+    sv = None
+    if save:
+        sv = dict(g=g, xres=xres, h_pre=h_pre, cat_pre=cat_pre, r_pre=r_pre, out=out, coef_h=coef_h, save_h=save_h,
+                  coef_c=coef_c, save_c=save_c, coef_r=coef_r, save_r=save_r, training=training)
+    return out, sv
+
+
+def tcn_backward(P, sv, dout, need_dg=True, need_dxres=True):
+    """Returns (dg, dxres, grads).  dxres is None for rmode 'zero'; for 'identity' it is the
+    masked upstream gradient itself (caller adds it)."""
+    g, xres, h_pre, cat_pre, r_pre, out = sv['g'], sv['xres'], sv['h_pre'], sv['cat_pre'], sv['r_pre'], sv['out']
+    training = sv['training']
+    N, Cin, T, V = g.shape
+    Cb, nb, s, Cout = P.Cb, P.nb, P.stride, P.Cout
+    T2 = cat_pre.shape[2]
+    cnt1, cnt2 = N * T * V, N * T2 * V
+    Ch = (nb + 1) * Cb
+    G = {}
+    dz, part = ops.add_act_bwd(dout, out, P.relu, cat_pre, r_pre, want_dz=bool(P.relu))
+    if dz is None:
+        dz = dout
+    coefb_c = torch.empty(3, Cout, device=g.device)
+    G['bn_t'] = []
+    G['bt'] = []
+    for b in range(nb):
+        dgam, dbet, dbias = P.bn_t[b].bwd(part, b * Cb, cnt2, sv['save_c'], b * Cb, training, coefb_c, b * Cb, True)
+        G['bn_t'].append((dgam, dbet))
+        G['bt'].append(dbias)
+    dgam, dbet, _ = P.bn_pool.bwd(part, nb * Cb, cnt2, sv['save_c'], nb * Cb, training, coefb_c, nb * Cb)
+    G['bn_pool'] = (dgam, dbet)
+    dgam, dbet, G['bl'] = P.bn_l.bwd(part, (nb + 1) * Cb, cnt2, sv['save_c'], (nb + 1) * Cb, training, coefb_c,
+                                     (nb + 1) * Cb, True)
+    G['bn_l'] = (dgam, dbet)
+
+    def gcat(coff):
+        return S(dz, cat_pre, coefb_c, coff=coff)
+
+    dh = torch.empty(N, Ch, T, V, device=g.device)
+    coefb_h = torch.empty(3, Ch, device=g.device)
+    G['Wt'] = []
+    G['bn_in'] = []
+    dbin = []
+    for b in range(nb):
+        k, d = P.ks[b], P.dils[b]
+        pad = _tpad(k, d)
+        _, hp = ops.conv(gcat(b * Cb), K=Cb, w=P.Wt[b], bias=None, M=Cb, KT=k, dil=d, stride=1,
+                         pad=(k - 1) * d - pad, wmode=1, up=s, y=dh, ycoff=b * Cb, T_out=T,
+                         mask=S(h_pre, coef=sv['coef_h'], coff=b * Cb), aux=h_pre, auxcoff=b * Cb, stats=True)
+        G['Wt'].append(ops.wgrad(gcat(b * Cb), S(h_pre, coef=sv['coef_h'], coff=b * Cb, act=RELU), M=Cb, K=Cb,
+                                 KT=k, dil=d, stride=s, pad=pad))
+        dgam, dbet, dbias = P.bn_in[b].bwd(hp, b * Cb, cnt1, sv['save_h'], b * Cb, training, coefb_h, b * Cb, True)
+        G['bn_in'].append((dgam, dbet))
+        dbin.append(dbias)
+    hp = ops.maxpool_bwd(gcat(nb * Cb), S(h_pre, coef=sv['coef_h'], coff=nb * Cb, act=RELU), Cb, s, dh, nb * Cb)
+    dgam, dbet, dbias = P.bn_in[nb].bwd(hp, nb * Cb, cnt1, sv['save_h'], nb * Cb, training, coefb_h, nb * Cb, True)
+    G['bn_in'].append((dgam, dbet))
+    dbin.append(dbias)
+    G['bin'] = torch.cat(dbin)
+    gs = S(g)
+    gyh = S(dh, h_pre, coefb_h)
+    G['Win'] = ops.wgrad(gyh, gs, M=Ch, K=Cin)
+    G['Wl'] = ops.wgrad(gcat((nb + 1) * Cb), gs, M=Cb, K=Cin, stride=s)
+    dg = None
+    if need_dg:
+        dg, _ = ops.conv(gyh, K=Ch, w=P.Win, bias=None, M=Cin, wmode=1)
+        ops.conv(gcat((nb + 1) * Cb), K=Cb, w=P.Wl, bias=None, M=Cin, wmode=1, y=dg, T_out=T2, ostride=s, add1=dg)
+    dxres = None
+    if P.rmode == 'identity':
+        dxres = dz
+    elif P.rmode == 'conv':
+        coefb_r = torch.empty(3, Cout, device=g.device)
+        dgam, dbet, G['br'] = P.bnr.bwd(part[2:4], 0, cnt2, sv['save_r'], 0, training, coefb_r, 0, True)
+        G['bnr'] = (dgam, dbet)
+        gyr = S(dz, r_pre, coefb_r)
+        rk = P.rk
+        rpad = (rk - 1) // 2
+        G['Wr'] = ops.wgrad(gyr, S(xres), M=Cout, K=xres.shape[1], KT=rk, stride=s, pad=rpad)
+        if need_dxres:
+            Tx = xres.shape[2]
+            if rk == 1:
+                dxres = torch.zeros_like(xres) if s > 1 else torch.empty_like(xres)
+                ops.conv(gyr, K=Cout, w=P.Wr, bias=None, M=xres.shape[1], wmode=1, y=dxres, T_out=T2, ostride=s)
+            else:
+                dxres, _ = ops.conv(gyr, K=Cout, w=P.Wr, bias=None, M=xres.shape[1], KT=rk, stride=1,
+                                    pad=(rk - 1) - rpad, wmode=1, up=s, T_out=Tx)
+    return dg, dxres, G
+
+
+# ===========================================================================
+# autograd wrappers.  Parameter order is fixed by the *_tensors() helpers of
+# the modules (models/ctrgcn.py); cfg objects carry everything non-differentiable.
+# ===========================================================================
+def _needs(ctx):
+    return any(ctx.needs_input_grad)
+
+
+class UnitGCNFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, x, *params):
+        P = mod._pack(params)
+        g, sv = gcn_forward(x, P, mod.training, save=_needs(ctx))
+        ctx.mod, ctx.P, ctx.sv = mod, P, sv
+        return g
+
+    @staticmethod
+    def backward(ctx, dg):
+        dx, G = gcn_backward(ctx.P, ctx.sv, dg.contiguous(), need_dx=ctx.needs_input_grad[1])
+        ctx.sv = None
+        return (None, dx) + tuple(ctx.mod._route(G))
+
+
+class MSTCNFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, x, *params):
+        P = mod._pack(params)
+        out, sv = tcn_forward(x, P, mod.training, save=_needs(ctx))
+        ctx.mod, ctx.P, ctx.sv = mod, P, sv
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        need = ctx.needs_input_grad[1]
+        dg, dxres, G = tcn_backward(ctx.P, ctx.sv, dout.contiguous(), need_dg=need, need_dxres=need)
+        ctx.sv = None
+        if need and dxres is not None:
+            dg = dg + dxres            # stand-alone module with its own residual (rare path)
+        return (None, dg) + tuple(ctx.mod._route(G))
+
+
+class TCNGCNUnitFn(torch.autograd.Function):
+    """relu(tcn1(gcn1(x)) + residual(x)) as one autograd node (models/ctrgcn.py:282-284)."""
+
+    @staticmethod
+    def forward(ctx, mod, x, ngcn, *params):
+        Pg = mod.gcn1._pack(params[:ngcn])
+        Pt = mod._pack_tcn(params[ngcn:])
+        save = _needs(ctx)
+        training = mod.training
+        g, svg = gcn_forward(x, Pg, training, save)
+        out, svt = tcn_forward(g, Pt, training, save, xres=x)
+        ctx.mod, ctx.Pg, ctx.Pt, ctx.svg, ctx.svt, ctx.ngcn = mod, Pg, Pt, svg, svt, ngcn
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        need_dx = ctx.needs_input_grad[1]
+        dg, dxres, Gt = tcn_backward(ctx.Pt, ctx.svt, dout.contiguous(), need_dg=True, need_dxres=need_dx)
+        ctx.svt = None
+        dx, Gg = gcn_backward(ctx.Pg, ctx.svg, dg, need_dx=need_dx, extra_dx=dxres)
+        ctx.svg = None
+        return (None, dx, None) + tuple(ctx.mod.gcn1._route(Gg)) + tuple(ctx.mod._route_tcn(Gt))
+
+
+# ---------------------------------------------------------------------------
+# stand-alone CTRGC (single subset; A and alpha are forward() arguments)
+# ---------------------------------------------------------------------------
+class CTRGCFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, A, alpha, w1, b1, w2, b2, w3, b3, w4, b4):
+        N, Cin, T, V = x.shape
+        Cout, R = w3.shape[0], w1.shape[0]
+        W12 = torch.cat((w1.reshape(R, Cin), w2.reshape(R, Cin)))
+        B12 = torch.cat((b1, b2))
+        W3, W4 = w3.reshape(Cout, Cin), w4.reshape(1, Cout, R)
+        A3 = A.reshape(1, V, V).contiguous()
+        al = alpha.reshape(1).to(torch.float32).contiguous()
+        xs = S(x)
+        xbar = ops.tmean(xs, Cin)
+        pq, _ = ops.conv(S(xbar.view(1, Cin, N, V)), K=Cin, w=W12, bias=B12, M=2 * R)
+        pq = pq.view(2 * R, N, V)
+        y, _ = ops.ctrgc_fwd(xs, pq, W3, b3, W4, b4.reshape(1, Cout), A3, al, Cin, Cout, 1, R, stats=False)
+        ctx.sv = (x, xbar, pq, W12, W3, b3, W4, b4.reshape(1, Cout), A3, al)
+        ctx.shapes = (A.shape, alpha.shape, w1.shape, w3.shape, w4.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, xbar, pq, W12, W3, b3, W4, b4, A3, al = ctx.sv
+        N, Cin, T, V = x.shape
+        Cout, R = W3.shape[0], W4.shape[2]
+        xs = S(x)
+        dx3, db3, dA, dW4, db4, dal, dpq = ops.ctrgc_bwd(xs, pq, W3, b3, W4, b4, A3, al, Cin, Cout, 1, R,
+                                                         S(dy.contiguous()))
+        dpq4 = S(dpq.view(1, 2 * R, N, V))
+        dW12 = ops.wgrad(dpq4, S(xbar.view(1, Cin, N, V)), M=2 * R, K=Cin)
+        dB12 = dpq.sum((1, 2))
+        dW3 = ops.wgrad(S(dx3), xs, M=Cout, K=Cin)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dxbar, _ = ops.conv(dpq4, K=2 * R, w=W12, bias=None, M=Cin, wmode=1)
+            dx, _ = ops.conv(S(dx3), K=Cout, w=W3, bias=None, M=Cin, wmode=1, bcast=dxbar.view(Cin, N, V),
+                             bcast_scale=1.0 / T)
+        As, als, w1s, w3s, w4s = ctx.shapes
+        return (dx, dA.reshape(As), dal.reshape(als), dW12[:R].reshape(w1s), dB12[:R], dW12[R:].reshape(w1s),
+                dB12[R:], dW3.reshape(w3s), db3, dW4.reshape(w4s), db4.reshape(Cout))
+
+
+# ---------------------------------------------------------------------------
+# conv k x 1 + BatchNorm (TemporalConv, unit_tcn)
+# ---------------------------------------------------------------------------
+class ConvBNFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cfg, x, w, b, gamma, beta):
+        k, s, d, pad, bnmod = cfg
+        bn = BN(bnmod)
+        training = bnmod.training
+        N, Cin, T, V = x.shape
+        M = w.shape[0]
+        y_pre, part = ops.conv(S(x), K=Cin, w=w, bias=b, M=M, KT=k, dil=d, stride=s, pad=pad, stats=training)
+        T2 = y_pre.shape[2]
+        coef, save = _coef(M, x)
+        bn.fwd(part, 0, N * T2 * V, training, coef, save, 0)
+        out = ops.apply(S(y_pre, coef=coef), M)
+        ctx.sv = (x, w, y_pre, save, bn, training, cfg)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w, y_pre, save, bn, training, cfg = ctx.sv
+        k, s, d, pad, _ = cfg
+        dout = dout.contiguous()
+        N, Cin, T, V = x.shape
+        M, T2 = y_pre.shape[1], y_pre.shape[2]
+        _, part = ops.add_act_bwd(dout, None, 0, y_pre, None, want_dz=False)
+        coefb = torch.empty(3, M, device=x.device)
+        dgam, dbet, dbias = bn.bwd(part, 0, N * T2 * V, save, 0, training, coefb, 0, True)
+        gy = S(dout, y_pre, coefb)
+        dw = ops.wgrad(gy, S(x), M=M, K=Cin, KT=k, dil=d, stride=s, pad=pad)
+        dx = None
+        if ctx.needs_input_grad[1]:
+            if k == 1:
+                dx = torch.zeros_like(x) if s > 1 else torch.empty_like(x)
+                ops.conv(gy, K=M, w=w, bias=None, M=Cin, wmode=1, y=dx, T_out=T2, ostride=s)
+            else:
+                dx, _ = ops.conv(gy, K=M, w=w, bias=None, M=Cin, KT=k, dil=d, stride=1, pad=(k - 1) * d - pad,
+                                 wmode=1, up=s, T_out=T)
+        return None, dx, dw, dbias, dgam, dbet

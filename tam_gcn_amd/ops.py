@@ -1,0 +1,273 @@
+"""Thin Python plumbing over the C ABI: device pointers out of torch tensors,
+output allocation through torch's caching allocator, the current HIP stream.
+No arithmetic happens here."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import Src, ConvDesc, WgradDesc, CtrgcDesc
+
+RELU = 1
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if not (t.is_cuda and t.is_contiguous()):
+        raise RuntimeError('tam_gcn_amd: expected a contiguous HIP (cuda) tensor; there is no CPU path')
+    if t.dtype not in (torch.float32, torch.int64):
+        raise RuntimeError(f'tam_gcn_amd: unsupported dtype {t.dtype}')
+    return t.data_ptr()
+
+
+class S:
+    """A fused-prologue operand: value = act(c1*x1 + c2*x2 + c0) over (N, ctot, T, V)."""
+    __slots__ = ('x1', 'x2', 'coef', 'coff', 'act', 'ctot')
+
+    def __init__(self, x1, x2=None, coef=None, coff=0, act=0):
+        self.x1, self.x2, self.coef, self.coff, self.act = x1, x2, coef, coff, act
+        self.ctot = x1.shape[1]
+        if x2 is not None and x2.shape != x1.shape:
+            raise RuntimeError('tam_gcn_amd: x1/x2 geometry mismatch')
+        if coef is not None and tuple(coef.shape) != (3, self.ctot):
+            raise RuntimeError(f'tam_gcn_amd: coef shape {tuple(coef.shape)} != (3,{self.ctot})')
+
+    def c(self):
+        return Src(_ptr(self.x1), _ptr(self.x2), _ptr(self.coef), self.ctot, self.coff, self.act)
+
+
+def _lib_():
+    return _lib.load()
+
+
+def empty(*shape, like):
+    return torch.empty(shape, device=like.device, dtype=torch.float32)
+
+
+# ---------------------------------------------------------------------------
+def conv(src, K, w, bias, M, KT=1, dil=1, stride=1, pad=0, wmode=0, up=1,
+         y=None, ycoff=0, T_out=None, T_y=None, ostride=1, add1=None, add2=None,
+         bcast=None, bcast_scale=0.0, mask=None, aux=None, auxcoff=0, stats=False):
+    """y (N, yctot, T_y, V); returns (y, stats_part [2][yctot][nparts] or None)."""
+    x = src.x1
+    N, _, T_in, V = x.shape
+    if T_out is None:
+        T_out = (T_in + 2 * pad - dil * (KT - 1) - 1) // stride + 1
+    if y is None:
+        if T_y is None:
+            T_y = T_out
+        y = empty(N, M, T_y, V, like=x)
+    else:
+        T_y = y.shape[2]
+    d = ConvDesc()
+    d.src = src.c()
+    d.N, d.K, d.T_in, d.V = N, K, T_in, V
+    d.w, d.bias = _ptr(w), _ptr(bias)
+    d.M, d.KT, d.dil, d.stride, d.pad = M, KT, dil, stride, pad
+    d.wmode, d.up = wmode, up
+    d.y, d.yctot, d.ycoff = _ptr(y), y.shape[1], ycoff
+    d.T_out, d.T_y, d.ostride = T_out, T_y, ostride
+    d.add1, d.add2, d.bcast, d.bcast_scale = _ptr(add1), _ptr(add2), _ptr(bcast), bcast_scale
+    mc = None
+    if mask is not None:
+        mc = mask.c()
+        d.mask = C.pointer(mc)
+    if aux is not None:
+        d.aux, d.auxctot, d.auxcoff = _ptr(aux), aux.shape[1], auxcoff
+    part = None
+    lib = _lib_()
+    if stats:
+        nparts = lib.tamgcn_conv_nparts(C.byref(d))
+        if nparts <= 0:
+            raise RuntimeError('tamgcn_conv: no tiling for this shape')
+        part = empty(2, y.shape[1], nparts, like=x)
+        d.stats_part, d.stats_ctot, d.stats_coff = _ptr(part), y.shape[1], ycoff
+    _lib.check(lib.tamgcn_conv(C.byref(d), _stream()), 'tamgcn_conv')
+    return y, part
+
+
+def wgrad(gy, src, M, K, KT=1, dil=1, stride=1, pad=0):
+    """Returns dW (M, K, KT, 1)."""
+    N, _, T_out, V = gy.x1.shape
+    T_in = src.x1.shape[2]
+    tiles = ((M + 63) // 64) * ((K + 63) // 64) if KT == 1 and not (M <= 32 and K <= 32) \
+        else ((M + 31) // 32) * ((K + 31) // 32)
+    nsplit = max(1, min(N, 768 // max(1, tiles)))
+    part = empty(nsplit, M, K, KT, like=gy.x1)
+    d = WgradDesc()
+    d.gy, d.src = gy.c(), src.c()
+    d.N, d.M, d.K, d.T_in, d.T_out, d.V = N, M, K, T_in, T_out, V
+    d.KT, d.dil, d.stride, d.pad = KT, dil, stride, pad
+    d.part, d.nsplit = _ptr(part), nsplit
+    lib = _lib_()
+    _lib.check(lib.tamgcn_wgrad(C.byref(d), _stream()), 'tamgcn_wgrad')
+    if nsplit == 1:
+        return part.view(M, K, KT, 1)
+    return reduce_sum(part, nsplit).view(M, K, KT, 1)
+
+
+def reduce_sum(part, nsplit, scale=1.0, out=None, accumulate=False):
+    """part [nsplit][...] -> sum over the leading dim."""
+    count = part.numel() // nsplit
+    if out is None:
+        out = torch.empty(part.shape[1:], device=part.device, dtype=torch.float32)
+    _lib.check(_lib_().tamgcn_reduce_sum(_ptr(part), nsplit, count, count, scale, int(accumulate), _ptr(out), _stream()),
+               'tamgcn_reduce_sum')
+    return out
+
+
+# ---------------------------------------------------------------------------
+def bn_fwd_finalize(part, part_coff, count, gamma, beta, rmean, rvar, nbt, momentum, eps, training,
+                    coef, save, coff, C_):
+    lib = _lib_()
+    if part is not None:
+        pctot, nparts = part.shape[1], part.shape[2]
+    else:
+        pctot, nparts = 0, 0
+    _lib.check(lib.tamgcn_bn_fwd_finalize(_ptr(part), pctot, part_coff, nparts, float(count),
+                                          _ptr(gamma), _ptr(beta), _ptr(rmean), _ptr(rvar), _ptr(nbt),
+                                          momentum, eps, int(training), _ptr(coef), _ptr(save),
+                                          coef.shape[1], coff, C_, _stream()), 'tamgcn_bn_fwd_finalize')
+
+
+def bn_bwd_finalize(part, part_coff, count, gamma, save, save_coff, training, dgamma, dbeta, dbias, coef, coff, C_):
+    lib = _lib_()
+    _lib.check(lib.tamgcn_bn_bwd_finalize(_ptr(part), part.shape[1], part_coff, part.shape[2], float(count),
+                                          _ptr(gamma), _ptr(save), save.shape[1], save_coff, int(training),
+                                          _ptr(dgamma), _ptr(dbeta), _ptr(dbias), _ptr(coef), coef.shape[1], coff, C_,
+                                          _stream()), 'tamgcn_bn_bwd_finalize')
+
+
+# ---------------------------------------------------------------------------
+def tmean(src, C_):
+    N, _, T, V = src.x1.shape
+    xbar = empty(C_, N, V, like=src.x1)
+    sc = src.c()
+    _lib.check(_lib_().tamgcn_tmean(C.byref(sc), N, C_, T, V, _ptr(xbar), _stream()), 'tamgcn_tmean')
+    return xbar
+
+
+def _ctrgc_desc(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R):
+    N, _, T, V = x.x1.shape
+    d = CtrgcDesc()
+    d.N, d.Cin, d.Cout, d.S, d.R, d.T, d.V = N, Cin, Cout, S, R, T, V
+    d.x = x.c()
+    d.pq, d.w3, d.b3, d.w4, d.b4, d.A, d.alpha = (_ptr(pq), _ptr(w3), _ptr(b3), _ptr(w4), _ptr(b4), _ptr(A), _ptr(alpha))
+    return d
+
+
+def ctrgc_fwd(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, stats):
+    N, _, T, V = x.x1.shape
+    d = _ctrgc_desc(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R)
+    y = empty(N, Cout, T, V, like=x.x1)
+    part = empty(2, Cout, N, like=x.x1) if stats else None
+    _lib.check(_lib_().tamgcn_ctrgc_fwd(C.byref(d), _ptr(y), _ptr(part), _stream()), 'tamgcn_ctrgc_fwd')
+    return y, part
+
+
+def ctrgc_bwd(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy):
+    """Returns dx3 (N,S*Cout,T,V), db3 [S*Cout], dA [S,V,V], dw4 [S,Cout,R], db4 [S,Cout], dalpha [1], dpq [S*2*R,N,V]."""
+    N, _, T, V = x.x1.shape
+    lib = _lib_()
+    d = _ctrgc_desc(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R)
+    dyc = dy.c()
+    like = x.x1
+    dx3 = empty(N, S * Cout, T, V, like=like)
+    db3_part = empty(N, S * Cout, like=like)
+    _lib.check(lib.tamgcn_ctrgc_bwd_dx3(C.byref(d), C.byref(dyc), _ptr(dx3), _ptr(db3_part), _stream()),
+               'tamgcn_ctrgc_bwd_dx3')
+    nct = Cout // 16
+    dA_part = empty(N * nct, S, V, V, like=like)
+    dw4_part = empty(N, S, Cout, R, like=like)
+    db4_part = empty(N, S, Cout, like=like)
+    dal_part = empty(N * nct, 1, like=like)
+    dpq = torch.zeros(S * 2 * R, N, V, device=like.device, dtype=torch.float32)
+    _lib.check(lib.tamgcn_ctrgc_bwd_de(C.byref(d), C.byref(dyc), _ptr(dA_part), _ptr(dw4_part), _ptr(db4_part),
+                                       _ptr(dal_part), _ptr(dpq), _stream()), 'tamgcn_ctrgc_bwd_de')
+    return (dx3, reduce_sum(db3_part, N), reduce_sum(dA_part, N * nct), reduce_sum(dw4_part, N),
+            reduce_sum(db4_part, N), reduce_sum(dal_part, N * nct), dpq)
+
+
+# ---------------------------------------------------------------------------
+def gcn_tail_fwd(y, o, res):
+    N, _, T, V = y.x1.shape
+    Cc = y.ctot
+    g = empty(N, Cc, T, V, like=y.x1)
+    yc, oc = y.c(), o.c()
+    rc = res.c() if res is not None else None
+    _lib.check(_lib_().tamgcn_gcn_tail_fwd(C.byref(yc), C.byref(oc), C.byref(rc) if rc is not None else None,
+                                           N, Cc, T, V, _ptr(g), _stream()), 'tamgcn_gcn_tail_fwd')
+    return g
+
+
+def gcn_tail_bwd(dg, g, o):
+    N, Cc, T, V = g.shape
+    dsum, doz = torch.empty_like(g), torch.empty_like(g)
+    part = empty(2, Cc, N, like=g)
+    oc = o.c()
+    _lib.check(_lib_().tamgcn_gcn_tail_bwd(_ptr(dg), _ptr(g), C.byref(oc), N, Cc, T, V, _ptr(dsum), _ptr(doz),
+                                           _ptr(part), _stream()), 'tamgcn_gcn_tail_bwd')
+    return dsum, doz, part
+
+
+def gcn_mid_bwd(dsum, ddiff, y_pre, r_pre, want_dres):
+    N, Cc, T, V = dsum.shape
+    dyb = torch.empty_like(dsum)
+    dres = torch.empty_like(dsum) if want_dres else None
+    part = empty(4 if r_pre is not None else 2, Cc, N, like=dsum)
+    _lib.check(_lib_().tamgcn_gcn_mid_bwd(_ptr(dsum), _ptr(ddiff), _ptr(y_pre), _ptr(r_pre), N, Cc, T, V,
+                                          _ptr(dyb), _ptr(dres), _ptr(part), _stream()), 'tamgcn_gcn_mid_bwd')
+    return dyb, dres, part
+
+
+def maxpool_fwd(src, C_, stride, y, ycoff, stats):
+    N, _, T_in, V = src.x1.shape
+    T_out = y.shape[2]
+    part = empty(2, y.shape[1], N, like=y) if stats else None
+    sc = src.c()
+    _lib.check(_lib_().tamgcn_maxpool_fwd(C.byref(sc), N, C_, T_in, V, stride, _ptr(y), y.shape[1], ycoff, T_out,
+                                          _ptr(part), _stream()), 'tamgcn_maxpool_fwd')
+    return part
+
+
+def maxpool_bwd(gy, src, C_, stride, d, dcoff):
+    N, _, T_in, V = src.x1.shape
+    T_out = gy.x1.shape[2]
+    part = empty(2, d.shape[1], N, like=d)
+    gc, sc = gy.c(), src.c()
+    _lib.check(_lib_().tamgcn_maxpool_bwd(C.byref(gc), C.byref(sc), N, C_, T_in, T_out, V, stride, _ptr(d),
+                                          d.shape[1], dcoff, _ptr(part), _stream()), 'tamgcn_maxpool_bwd')
+    return part
+
+
+def add_act_fwd(a, res, relu, C_):
+    N, _, T, V = a.x1.shape
+    out = empty(N, C_, T, V, like=a.x1)
+    ac = a.c()
+    rc = res.c() if res is not None else None
+    _lib.check(_lib_().tamgcn_add_act_fwd(C.byref(ac), C.byref(rc) if rc is not None else None, int(relu),
+                                          N, C_, T, V, _ptr(out), _stream()), 'tamgcn_add_act_fwd')
+    return out
+
+
+def add_act_bwd(dout, out, relu, a_pre, r_pre, want_dz):
+    N, Cc, T, V = dout.shape
+    dz = torch.empty_like(dout) if want_dz else None
+    part = empty(4 if r_pre is not None else 2, Cc, N, like=dout)
+    _lib.check(_lib_().tamgcn_add_act_bwd(_ptr(dout), _ptr(out), int(relu), _ptr(a_pre), _ptr(r_pre), N, Cc, T, V,
+                                          _ptr(dz), _ptr(part), _stream()), 'tamgcn_add_act_bwd')
+    return dz, part
+
+
+def apply(src, C_, y=None, ycoff=0):
+    N, _, T, V = src.x1.shape
+    if y is None:
+        y = empty(N, C_, T, V, like=src.x1)
+    sc = src.c()
+    _lib.check(_lib_().tamgcn_apply(C.byref(sc), N, C_, T, V, _ptr(y), y.shape[1], ycoff, _stream()), 'tamgcn_apply')
+    return y

@@ -1,0 +1,58 @@
+"""Case table shared by make_golden.py (reference side) and the tests
+(oracle / HIP side).  Pure data: (tag, kind, ctor kwargs, x shape, x seed)."""
+
+COT_SEED = 777
+
+# kind -> list of (tag, ctor kwargs, input shape (N,C,T,V))
+MODULE_CASES = [
+    # CTRGC (reference models/ctrgcn.py:150-177); graph subset index 1 + noise as A, alpha 0.6
+    ('ctrgc_3_64',        'CTRGC', dict(in_channels=3, out_channels=64),   (2, 3, 8, 20),  11),
+    ('ctrgc_64_64',       'CTRGC', dict(in_channels=64, out_channels=64),  (2, 64, 8, 20), 11),
+    ('ctrgc_64_128_v25',  'CTRGC', dict(in_channels=64, out_channels=128), (1, 64, 6, 25), 11),
+    # unit_gcn (:196-263)
+    ('gcn_3_64',          'unit_gcn', dict(in_channels=3, out_channels=64),    (2, 3, 8, 20),   12),
+    ('gcn_64_64',         'unit_gcn', dict(in_channels=64, out_channels=64),   (2, 64, 8, 20),  12),
+    ('gcn_64_128',        'unit_gcn', dict(in_channels=64, out_channels=128),  (2, 64, 6, 20),  12),
+    ('gcn_128_128_v25',   'unit_gcn', dict(in_channels=128, out_channels=128), (1, 128, 5, 25), 12),
+    # TemporalConv (:52-69)
+    ('tconv_16_k5_s1_d1', 'TemporalConv', dict(in_channels=16, out_channels=16, kernel_size=5, stride=1, dilation=1), (2, 16, 13, 20), 13),
+    ('tconv_16_k5_s2_d2', 'TemporalConv', dict(in_channels=16, out_channels=16, kernel_size=5, stride=2, dilation=2), (2, 16, 13, 20), 13),
+    ('tconv_32_k5_s2_d1', 'TemporalConv', dict(in_channels=32, out_channels=32, kernel_size=5, stride=2, dilation=1), (2, 32, 12, 20), 13),
+    # unit_tcn (:179-193)
+    ('utcn_64_128_k1_s2', 'unit_tcn', dict(in_channels=64, out_channels=128, kernel_size=1, stride=2), (2, 64, 13, 20), 14),
+    ('utcn_16_16_k9_s1',  'unit_tcn', dict(in_channels=16, out_channels=16, kernel_size=9, stride=1),  (2, 16, 12, 20), 14),
+    # MultiScale_TemporalConv (:72-147), as TCN_GCN_unit builds it (k=5, dilations [1,2])
+    ('mstcn_64_s1',         'MultiScale_TemporalConv', dict(in_channels=64, out_channels=64, kernel_size=5, stride=1, dilations=[1, 2], residual=False),   (2, 64, 13, 20), 15),
+    ('mstcn_64_s2',         'MultiScale_TemporalConv', dict(in_channels=64, out_channels=64, kernel_size=5, stride=2, dilations=[1, 2], residual=False),   (2, 64, 13, 20), 15),
+    ('mstcn_128_s2_t12',    'MultiScale_TemporalConv', dict(in_channels=128, out_channels=128, kernel_size=5, stride=2, dilations=[1, 2], residual=False), (2, 128, 12, 20), 15),
+    ('mstcn_64_s1_res',     'MultiScale_TemporalConv', dict(in_channels=64, out_channels=64, kernel_size=5, stride=1, dilations=[1, 2], residual=True),    (2, 64, 8, 20), 15),
+    ('mstcn_64_128_s2_res', 'MultiScale_TemporalConv', dict(in_channels=64, out_channels=128, kernel_size=5, stride=2, dilations=[1, 2], residual=True),   (2, 64, 9, 25), 15),
+    ('mstcn_default_d4',    'MultiScale_TemporalConv', dict(in_channels=48, out_channels=48),                                                             (2, 48, 11, 20), 15),
+    # TCN_GCN_unit (:266-284)
+    ('unit_3_64_nores',     'TCN_GCN_unit', dict(in_channels=3, out_channels=64, stride=1, residual=False),  (2, 3, 13, 20),  16),
+    ('unit_64_64',          'TCN_GCN_unit', dict(in_channels=64, out_channels=64, stride=1, residual=True),  (2, 64, 13, 20), 16),
+    ('unit_64_128_s2',      'TCN_GCN_unit', dict(in_channels=64, out_channels=128, stride=2, residual=True), (2, 64, 13, 20), 16),
+    ('unit_64_128_s2_v25',  'TCN_GCN_unit', dict(in_channels=64, out_channels=128, stride=2, residual=True), (2, 64, 10, 25), 16),
+]
+
+NEEDS_A = ('unit_gcn', 'TCN_GCN_unit')      # ctor takes the (3,V,V) graph array
+
+_UCLA = dict(num_class=10, num_point=20, num_person=1, graph='graph.ucla.Graph',
+             graph_args=dict(labeling_mode='spatial'))
+_NTU = dict(num_class=60, num_point=25, num_person=2, graph='graph.ntu_rgb_d.Graph',
+            graph_args=dict(labeling_mode='spatial'))
+
+MODEL_CASES = [
+    ('ucla_t13', _UCLA, (2, 3, 13, 20, 1)),
+    ('ucla_t52', _UCLA, (2, 3, 52, 20, 1)),     # the reference's real clip length
+    ('ucla_t64', _UCLA, (4, 3, 64, 20, 1)),     # BASELINE.json's benchmark shape
+    ('ntu_t20',  _NTU,  (2, 3, 20, 25, 2)),
+]
+MODEL_PARAM_SEED = 42
+MODEL_X_SEED = 21
+MODEL_LABEL_SEED = 22
+MODEL_INIT_SEED = 1234
+
+
+def tag_seed(tag):
+    return sum(map(ord, tag))

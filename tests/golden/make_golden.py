@@ -1,0 +1,172 @@
+"""Golden-vector generator.  Runs ONLY in the build container: imports the
+reference's own models/ctrgcn.py + graph/ from /root/reference (read-only,
+PYTHONDONTWRITEBYTECODE=1) and writes *data only* (inputs, parameters,
+outputs, gradients) into tests/golden/*.npz.  No reference source travels.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference has no tests or golden vectors of its own, so
+these files are what pins the oracle (oracle/ctrgcn_oracle.py) and, through
+it and directly, the HIP path.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from params import fill_state_, make_input, make_labels, digest  # noqa: E402
+from cases import (MODULE_CASES, MODEL_CASES, NEEDS_A, COT_SEED, MODEL_PARAM_SEED, MODEL_X_SEED,  # noqa: E402
+                   MODEL_LABEL_SEED, MODEL_INIT_SEED, tag_seed)
+
+REF = '/root/reference'
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+import graph.ucla, graph.ntu_rgb_d          # noqa: E402,E401  (reference's)
+from models import ctrgcn as R               # noqa: E402      (reference's)
+
+torch.set_num_threads(8)
+torch.manual_seed(0)
+
+
+def np32(t):
+    return t.detach().cpu().numpy()
+
+
+FULL_MAX = 20000          # tensors up to this many elements are stored in full
+
+
+def put(out, key, t):
+    """Store small tensors in full, large ones as a digest (key + '#digest')."""
+    if t.numel() <= FULL_MAX:
+        out[key] = np32(t).copy()
+    else:
+        out[key + '#digest'] = digest(t)
+
+
+def run_module(mod, x, out, tag, extra_fwd=None):
+    """Parameters come from fill_state_(seed=tag_seed(tag)) (regenerable, not
+    stored).  Train-mode fwd + bwd of sum(y * cot) with a fixed cotangent,
+    buffers after the step, then an eval-mode forward."""
+    fill_state_(mod.state_dict(), seed=tag_seed(tag))
+    mod.train()
+    x = x.clone().requires_grad_(True)
+    y = extra_fwd(mod, x) if extra_fwd else mod(x)
+    cot = make_input(tuple(y.shape), seed=COT_SEED)
+    (y * cot).sum().backward()
+    out[f'{tag}/x_shape'] = np.array(x.shape)
+    put(out, f'{tag}/y', y)
+    put(out, f'{tag}/dx', x.grad)
+    for k, p in mod.named_parameters():
+        put(out, f'{tag}/grad/{k}', p.grad)
+    for k, b in mod.named_buffers():
+        put(out, f'{tag}/buf_after/{k}', b)
+    mod.eval()
+    with torch.no_grad():
+        ye = extra_fwd(mod, x) if extra_fwd else mod(x)
+    put(out, f'{tag}/y_eval', ye)
+
+
+def modules():
+    out = {}
+    A_by_V = {20: graph.ucla.Graph().A, 25: graph.ntu_rgb_d.Graph().A}
+    for tag, kind, kw, shape, xseed in MODULE_CASES:
+        V = shape[-1]
+        cls = getattr(R, kind)
+        x = make_input(shape, xseed)
+        if kind == 'CTRGC':
+            m = cls(**kw)
+            A = torch.from_numpy(A_by_V[V][1].astype(np.float32))
+            A = (A + 0.05 * make_input((V, V), 5)).requires_grad_(True)
+            alpha = torch.tensor([0.6], requires_grad=True)
+            run_module(m, x, out, tag, extra_fwd=lambda mod, xx: mod(xx, A, alpha))
+            out[f'{tag}/A'] = np32(A)
+            out[f'{tag}/dA'] = np32(A.grad)
+            out[f'{tag}/dalpha'] = np32(alpha.grad)
+        elif kind in NEEDS_A:
+            kw = dict(kw)
+            cin, cout = kw.pop('in_channels'), kw.pop('out_channels')
+            m = cls(cin, cout, A_by_V[V], **kw)
+            run_module(m, x, out, tag)
+        else:
+            run_module(cls(**kw), x, out, tag)
+    np.savez_compressed(os.path.join(HERE, 'modules.npz'), **out)
+    print('modules.npz', len(out), 'arrays')
+
+
+def models():
+    out = {}
+    cases = MODEL_CASES
+    for tag, margs, shape in cases:
+        # (1) init parity: digest of the freshly-initialised reference state-dict
+        torch.manual_seed(MODEL_INIT_SEED)
+        m = R.Model(**margs)
+        keys = list(m.state_dict().keys())
+        out[f'{tag}/keys'] = np.array(keys)
+        out[f'{tag}/init_digest'] = np.stack([digest(v) for v in m.state_dict().values()])
+        # (2) seeded parameters, one train step (fwd + CE + bwd), then eval fwd
+        sd = m.state_dict()
+        fill_state_(sd, seed=MODEL_PARAM_SEED)
+        x = make_input(shape, seed=MODEL_X_SEED)
+        lab = make_labels(shape[0], margs['num_class'], seed=MODEL_LABEL_SEED)
+        m.train()
+        xg = x.clone().requires_grad_(True)
+        logits = m(xg)
+        loss = torch.nn.functional.cross_entropy(logits, lab)
+        loss.backward()
+        out[f'{tag}/logits_train'] = np32(logits)
+        out[f'{tag}/loss'] = np32(loss)
+        out[f'{tag}/dx'] = np32(xg.grad)
+        out[f'{tag}/param_keys'] = np.array([k for k, _ in m.named_parameters()])
+        out[f'{tag}/grad_digest'] = np.stack([digest(p.grad) for _, p in m.named_parameters()])
+        for k, p in m.named_parameters():
+            if k.endswith('PA') or k.endswith('alpha') or k.startswith('fc.'):
+                out[f'{tag}/grad/{k}'] = np32(p.grad)
+        out[f'{tag}/buf_keys'] = np.array([k for k, _ in m.named_buffers()])
+        out[f'{tag}/buf_digest'] = np.stack([digest(b) for _, b in m.named_buffers()])
+        m.eval()
+        with torch.no_grad():
+            le = m(x)
+            f1, f2 = m.extract_feature(x)
+        out[f'{tag}/logits_eval'] = np32(le)
+        out[f'{tag}/feat_digest'] = digest(f1)
+        out[f'{tag}/feat_shape'] = np.array(f1.shape)
+        # 3-D input form (N, T, V*C), reference models/ctrgcn.py:325-327 (M=1 only)
+        if shape[-1] == 1:
+            x3 = x[..., 0].permute(0, 2, 3, 1).contiguous().view(shape[0], shape[2], -1)
+            with torch.no_grad():
+                out[f'{tag}/logits_eval_3d'] = np32(m(x3))
+        print(tag, 'loss', float(loss.detach()))
+    # (3) k SGD steps (harness contract): SGD(m=0.9,nesterov,wd=1e-4)+CE
+    torch.manual_seed(7)
+    m = R.Model(**cases[0][1])
+    fill_state_(m.state_dict(), seed=43)
+    opt = torch.optim.SGD(m.parameters(), lr=0.05, momentum=0.9, nesterov=True, weight_decay=1e-4)
+    m.train()
+    losses = []
+    for step in range(3):
+        x = make_input((4, 3, 13, 20, 1), seed=100 + step)
+        lab = make_labels(4, 10, seed=200 + step)
+        opt.zero_grad()
+        loss = torch.nn.functional.cross_entropy(m(x), lab)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    out['sgd3/losses'] = np.array(losses, dtype=np.float64)
+    out['sgd3/keys'] = np.array(list(m.state_dict().keys()))
+    out['sgd3/state_digest'] = np.stack([digest(v) for v in m.state_dict().values()])
+    np.savez_compressed(os.path.join(HERE, 'models.npz'), **out)
+    print('models.npz', len(out), 'arrays')
+
+
+def graphs():
+    np.savez_compressed(os.path.join(HERE, 'graphs.npz'),
+                        ucla=graph.ucla.Graph().A, ntu=graph.ntu_rgb_d.Graph().A)
+
+
+if __name__ == '__main__':
+    graphs()
+    modules()
+    models()
