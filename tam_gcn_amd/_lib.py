@@ -87,6 +87,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64.so (SONAME libamdhip64.so.7) and finds it by file name
+    # through an RPATH; libtamgcn.so asks for libamdhip64.so.7.  If we were loaded first the
+    # process would end up with TWO HIP runtimes (ours from /opt/rocm, torch's bundled one) and
+    # our launches fail with "no ROCm-capable device".  Loading torch first makes the dynamic
+    # loader satisfy our DT_NEEDED with torch's already-loaded runtime (same SONAME).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise TamgcnLibraryError(
             f'{LIB_PATH} not found: the HIP extension is not built.  Run '

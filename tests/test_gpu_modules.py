@@ -1,0 +1,88 @@
+"""-m gpu: the HIP modules against (a) golden vectors generated from the reference and
+(b) the CPU oracle on the same seeded inputs.  Tolerances (fp32): outputs rel 1e-4 of
+max|y|; gradients rel 1e-3."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import (MODULE_CASES, COT_SEED, tag_seed, fill_state_, make_input, build_module, ctrgc_extras,
+                     oracle_run, golden_get, O)        # noqa: E402
+from params import digest                              # noqa: E402
+
+
+def _cmp(name, got, ref, rel, atol=0.0):
+    got = got.detach().cpu().double()
+    ref = torch.as_tensor(ref).double()
+    assert got.shape == ref.shape, f'{name}: {tuple(got.shape)} vs {tuple(ref.shape)}'
+    scale = float(ref.abs().max()) + 1e-6
+    err = float((got - ref).abs().max())
+    assert err <= rel * scale + atol, f'{name}: max-abs-err {err:.3e} > {rel:g} * {scale:.3e} + {atol:g}'
+
+
+def _cmp_gold(name, got, gold, key, rel, atol=0.0):
+    ref, is_dig = golden_get(gold, key)
+    if is_dig:
+        g = digest(got)
+        n = got.numel()
+        assert abs(g[0] - ref[0]) <= rel * abs(ref[1]) + 1e-6 * n, f'{name}: sum {g[0]} vs {ref[0]}'
+        assert abs(g[1] - ref[1]) <= rel * abs(ref[1]) + 1e-6 * n, f'{name}: abs-sum'
+        scale = (float(ref[2]) / n) ** 0.5 * 10 + 1e-6
+        assert np.abs(g[3:] - ref[3:]).max() <= rel * scale * 10, f'{name}: head/tail'
+    else:
+        _cmp(name, got, ref, rel, atol)
+
+
+@pytest.mark.parametrize('case', MODULE_CASES, ids=[c[0] for c in MODULE_CASES])
+def test_module_parity(case, golden_modules):
+    tag, kind, kw, shape, xseed = case
+    gold = golden_modules
+    dev = torch.device('cuda:0')
+    mod = build_module(kind, kw, shape[-1])
+    fill_state_(mod.state_dict(), seed=tag_seed(tag))
+    # oracle on the CPU with the same state
+    sd = {'m.' + k: v.detach().clone() for k, v in mod.state_dict().items()}
+    pnames = [k for k, _ in mod.named_parameters()]
+    for k in pnames:
+        sd['m.' + k].requires_grad_(True)
+    xo = make_input(shape, xseed).requires_grad_(True)
+    extras_o = ctrgc_extras(shape[-1]) if kind == 'CTRGC' else None
+    yo = oracle_run(kind, kw, sd, xo, True, extras_o)
+    cot = make_input(tuple(yo.shape), COT_SEED)
+    (yo * cot).sum().backward()
+    # HIP path
+    mod = mod.to(dev).train()
+    x = make_input(shape, xseed).to(dev).requires_grad_(True)
+    if kind == 'CTRGC':
+        A, alpha = ctrgc_extras(shape[-1], dev)
+        y = mod(x, A, alpha)
+    else:
+        y = mod(x)
+    (y * cot.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    REL_Y, REL_G = 1e-4, 1e-3
+    _cmp('y vs oracle', y, yo.detach(), REL_Y)
+    _cmp_gold('y vs golden', y, gold, f'{tag}/y', REL_Y * 2)
+    _cmp('dx vs oracle', x.grad, xo.grad, REL_G)
+    _cmp_gold('dx vs golden', x.grad, gold, f'{tag}/dx', REL_G * 2)
+    for k, p in mod.named_parameters():
+        assert p.grad is not None, f'no grad for {k}'
+        go = sd['m.' + k].grad
+        # biases of convs that feed a train-mode BatchNorm have an exactly-zero gradient in exact
+        # arithmetic; the reference produces ~1e-5 rounding noise there, hence the absolute floor
+        if k.endswith('bias') and float(go.abs().max()) < 2e-4:
+            assert float(p.grad.abs().max()) < 2e-3, k
+            continue
+        _cmp(f'grad {k} vs oracle', p.grad, go, REL_G, 2e-5)
+        _cmp_gold(f'grad {k} vs golden', p.grad, gold, f'{tag}/grad/{k}', REL_G * 2, 2e-5)
+    for k, b in mod.named_buffers():
+        _cmp(f'buffer {k}', b.float(), sd['m.' + k].detach().float(), 1e-4)
+    if kind == 'CTRGC':
+        _cmp('dA', A.grad, extras_o[0].grad, REL_G)
+        _cmp('dalpha', alpha.grad, extras_o[1].grad, REL_G)
+    # eval mode with the post-step running statistics
+    mod.eval()
+    with torch.no_grad():
+        ye = mod(x.detach(), A.detach(), alpha.detach()) if kind == 'CTRGC' else mod(x.detach())
+    _cmp_gold('y_eval vs golden', ye, gold, f'{tag}/y_eval', REL_Y * 2)

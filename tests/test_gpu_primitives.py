@@ -1,0 +1,232 @@
+"""-m gpu: each C-ABI primitive against a stock-PyTorch fp32 expression of the same
+arithmetic (computed on the CPU), on small ragged shapes."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from params import make_input          # noqa: E402
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def rnd(shape, seed, lo=-1.0, hi=1.0):
+    return make_input(shape, seed, lo, hi)
+
+
+def close(a, b, rtol=1e-4, atol=1e-5, msg=''):
+    np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=rtol, atol=atol, err_msg=msg)
+
+
+CONV_CASES = [
+    # N, K, M, T, V, KT, dil, stride
+    (2, 3, 64, 13, 20, 1, 1, 1),
+    (2, 20, 24, 13, 20, 1, 1, 1),
+    (3, 64, 192, 64, 20, 1, 1, 1),
+    (2, 16, 16, 13, 20, 5, 1, 1),
+    (2, 16, 16, 13, 20, 5, 2, 1),
+    (2, 32, 32, 12, 20, 5, 2, 2),
+    (2, 16, 16, 13, 20, 5, 1, 2),
+    (2, 64, 128, 13, 20, 1, 1, 2),
+    (1, 70, 40, 9, 25, 1, 1, 1),
+    (1, 16, 16, 12, 20, 9, 1, 1),
+    (1, 12, 12, 11, 20, 3, 3, 1),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: 'x'.join(map(str, c)))
+def test_conv_fwd_bwd_wgrad(case):
+    from tam_gcn_amd import ops
+    from tam_gcn_amd.ops import S
+    N, K, M, T, V, KT, dil, stride = case
+    pad = (KT + (KT - 1) * (dil - 1) - 1) // 2
+    x = rnd((N, K, T, V), 1).requires_grad_(True)
+    w = (rnd((M, K, KT, 1), 2) * 0.2).requires_grad_(True)
+    b = rnd((M,), 3).requires_grad_(True)
+    y = F.conv2d(x, w, b, stride=(stride, 1), padding=(pad, 0), dilation=(dil, 1))
+    cot = rnd(tuple(y.shape), 4)
+    (y * cot).sum().backward()
+    xd, wd, bd, cd = (t.detach().to(dev()) for t in (x, w, b, cot))
+    yg, part = ops.conv(S(xd), K=K, w=wd, bias=bd, M=M, KT=KT, dil=dil, stride=stride, pad=pad, stats=True)
+    close(yg, y, 1e-4, 1e-4, 'conv fwd')
+    s1 = part[0].sum(-1)
+    s2 = part[1].sum(-1)
+    close(s1, y.sum((0, 2, 3)), 1e-3, 1e-2, 'stats sum')
+    close(s2, (y * y).sum((0, 2, 3)), 1e-3, 1e-2, 'stats sumsq')
+    T2 = y.shape[2]
+    # data gradient
+    if KT == 1:
+        dx = torch.zeros_like(xd)
+        ops.conv(S(cd), K=M, w=wd, bias=None, M=K, wmode=1, y=dx, T_out=T2, ostride=stride)
+    else:
+        dx, _ = ops.conv(S(cd), K=M, w=wd, bias=None, M=K, KT=KT, dil=dil, stride=1, pad=(KT - 1) * dil - pad,
+                         wmode=1, up=stride, T_out=T)
+    close(dx, x.grad, 1e-4, 1e-4, 'conv bwd data')
+    dw = ops.wgrad(S(cd), S(xd), M=M, K=K, KT=KT, dil=dil, stride=stride, pad=pad)
+    close(dw, w.grad, 1e-4, 2e-4, 'conv wgrad')
+
+
+def test_conv_prologue_slices_mask_aux():
+    from tam_gcn_amd import ops
+    from tam_gcn_amd.ops import S
+    N, Ct, T, V = 2, 48, 13, 20
+    x1, x2 = rnd((N, Ct, T, V), 1), rnd((N, Ct, T, V), 2)
+    coef = rnd((3, Ct), 3)
+    w = rnd((16, 16, 5, 1), 4) * 0.2
+    val = torch.relu(coef[0][None, :, None, None] * x1 + coef[1][None, :, None, None] * x2 + coef[2][None, :, None, None])
+    ref = F.conv2d(val[:, 16:32], w, None, padding=(2, 0))
+    y = torch.full((N, 64, T, V), 7.0, device=dev())
+    add1 = rnd((N, 64, T, V), 5)
+    msk = rnd((N, 64, T, V), 6)
+    aux = rnd((N, 64, T, V), 7)
+    yg, part = ops.conv(S(x1.to(dev()), x2.to(dev()), coef.to(dev()), coff=16, act=1), K=16, w=w.to(dev()), bias=None,
+                        M=16, KT=5, pad=2, y=y, ycoff=32, add1=add1.to(dev()), mask=S(msk.to(dev()), coff=32),
+                        aux=aux.to(dev()), auxcoff=32, stats=True)
+    exp = (ref + add1[:, 32:48]) * (msk[:, 32:48] > 0)
+    close(yg[:, 32:48], exp, 1e-4, 1e-4)
+    assert float(yg[:, :32].min()) == 7.0 and float(yg[:, 48:].max()) == 7.0
+    close(part[0, 32:48].sum(-1), exp.sum((0, 2, 3)), 1e-3, 1e-2)
+    close(part[1, 32:48].sum(-1), (exp * aux[:, 32:48]).sum((0, 2, 3)), 1e-3, 1e-2)
+
+
+def test_bn_finalize_fwd_bwd():
+    from tam_gcn_amd import ops
+    from tam_gcn_amd.ops import S
+    N, C_, T, V = 3, 24, 7, 20
+    x = (rnd((N, C_, T, V), 1) * 2 + 0.5).requires_grad_(True)
+    g = (1 + 0.1 * rnd((C_,), 2)).requires_grad_(True)
+    b = rnd((C_,), 3).requires_grad_(True)
+    rm, rv = rnd((C_,), 4), rnd((C_,), 5, 0.5, 1.5)
+    rm0, rv0 = rm.clone(), rv.clone()
+    y = F.batch_norm(x, rm, rv, g, b, training=True, momentum=0.1, eps=1e-5)
+    cot = rnd(tuple(y.shape), 6)
+    (y * cot).sum().backward()
+    d = dev()
+    xd = x.detach().to(d)
+    part = torch.stack((xd.sum(3).sum(2).t().contiguous(), (xd * xd).sum(3).sum(2).t().contiguous()))   # [2][C][N]
+    coef = torch.empty(3, C_, device=d); save = torch.empty(2, C_, device=d)
+    rmd, rvd = rm0.to(d), rv0.to(d)
+    nbt = torch.zeros((), dtype=torch.int64, device=d)
+    ops.bn_fwd_finalize(part, 0, N * T * V, g.detach().to(d), b.detach().to(d), rmd, rvd, nbt, 0.1, 1e-5, True,
+                        coef, save, 0, C_)
+    yg = ops.apply(S(xd, coef=coef), C_)
+    close(yg, y, 1e-4, 1e-5)
+    close(rmd, rm, 1e-5, 1e-6); close(rvd, rv, 1e-5, 1e-6)
+    assert int(nbt) == 1
+    cd = cot.to(d)
+    _, bpart = ops.add_act_bwd(cd, None, 0, xd, None, want_dz=False)
+    coefb = torch.empty(3, C_, device=d)
+    dg = torch.empty(C_, device=d); db = torch.empty(C_, device=d); dbias = torch.empty(C_, device=d)
+    ops.bn_bwd_finalize(bpart, 0, N * T * V, g.detach().to(d), save, 0, True, dg, db, dbias, coefb, 0, C_)
+    close(dg, g.grad, 1e-4, 1e-4); close(db, b.grad, 1e-4, 1e-4)
+    dx = ops.apply(S(cd, xd, coefb), C_)
+    close(dx, x.grad, 1e-3, 1e-5)
+    assert float(dbias.abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize('shape', [(2, 3, 64, 9, 20, 3), (2, 64, 64, 20, 20, 3), (1, 128, 128, 5, 25, 3),
+                                   (2, 256, 256, 16, 20, 3), (2, 64, 32, 8, 20, 1)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_ctrgc_fused_fwd_bwd(shape):
+    """Fused CTRGC (S subsets summed) against the einsum formulation on the CPU."""
+    from tam_gcn_amd import ops
+    from tam_gcn_amd.ops import S
+    N, Cin, Cout, T, V, S_ = shape
+    R = 8 if Cin in (3, 9) else Cin // 8
+    x = rnd((N, Cin, T, V), 1).requires_grad_(True)
+    W12 = (rnd((S_ * 2 * R, Cin), 2) * (1.0 / Cin ** 0.5)).requires_grad_(True)
+    B12 = (rnd((S_ * 2 * R,), 3) * 0.1).requires_grad_(True)
+    W3 = (rnd((S_ * Cout, Cin), 4) * (1.0 / Cin ** 0.5)).requires_grad_(True)
+    B3 = (rnd((S_ * Cout,), 5) * 0.1).requires_grad_(True)
+    W4 = (rnd((S_, Cout, R), 6) * (1.0 / R ** 0.5)).requires_grad_(True)
+    B4 = (rnd((S_, Cout), 7) * 0.1).requires_grad_(True)
+    A = (rnd((S_, V, V), 8) * 0.3).requires_grad_(True)
+    alpha = torch.tensor([0.7], requires_grad=True)
+    xbar = x.mean(2)                                                      # N,Cin,V
+    pqr = torch.einsum('jc,ncv->jnv', W12, xbar) + B12[:, None, None]      # (S2R, N, V)
+    y = 0
+    for s in range(S_):
+        p = pqr[(2 * s) * R:(2 * s + 1) * R].permute(1, 0, 2)              # N,R,V
+        q = pqr[(2 * s + 1) * R:(2 * s + 2) * R].permute(1, 0, 2)
+        D = torch.tanh(p.unsqueeze(-1) - q.unsqueeze(-2))
+        E = alpha * (torch.einsum('cr,nruv->ncuv', W4[s], D) + B4[s][None, :, None, None]) + A[s][None, None]
+        x3 = torch.einsum('oc,nctv->notv', W3[s * Cout:(s + 1) * Cout], x) + B3[s * Cout:(s + 1) * Cout][None, :, None, None]
+        y = y + torch.einsum('ncuv,nctv->nctu', E, x3)
+    cot = rnd(tuple(y.shape), 9)
+    (y * cot).sum().backward(retain_graph=True)
+    d = dev()
+    t = lambda z: z.detach().to(d).contiguous()
+    xs = S(t(x))
+    xb = ops.tmean(xs, Cin)
+    close(xb, xbar.permute(1, 0, 2), 1e-5, 1e-6, 'tmean')
+    pq, _ = ops.conv(S(xb.view(1, Cin, N, V)), K=Cin, w=t(W12), bias=t(B12), M=S_ * 2 * R)
+    pq = pq.view(S_ * 2 * R, N, V)
+    close(pq, pqr, 1e-4, 1e-5, 'pq')
+    yg, part = ops.ctrgc_fwd(xs, pq, t(W3), t(B3), t(W4), t(B4), t(A), t(alpha), Cin, Cout, S_, R, stats=True)
+    close(yg, y, 2e-4, 2e-4, 'ctrgc fwd')
+    close(part[0].sum(-1), y.sum((0, 2, 3)), 1e-3, 1e-2, 'stats')
+    close(part[1].sum(-1), (y * y).sum((0, 2, 3)), 1e-3, 1e-2, 'stats2')
+    dx3, db3, dA, dW4, db4, dal, dpq = ops.ctrgc_bwd(xs, pq, t(W3), t(B3), t(W4), t(B4), t(A), t(alpha),
+                                                     Cin, Cout, S_, R, S(t(cot)))
+    gpq, = torch.autograd.grad((y * cot).sum(), pqr, retain_graph=True)
+    sc = lambda g: 2e-4 * (float(g.abs().max()) + 1e-3)
+    close(dA, A.grad, 1e-3, sc(A.grad), 'dA')
+    close(dW4, W4.grad, 1e-3, sc(W4.grad), 'dW4')
+    close(db4, B4.grad, 1e-3, sc(B4.grad), 'db4')
+    close(dal, alpha.grad, 1e-3, sc(alpha.grad), 'dalpha')
+    close(db3, B3.grad, 1e-3, sc(B3.grad), 'db3')
+    close(dpq, gpq, 1e-3, sc(gpq), 'dpq')
+    dW3 = ops.wgrad(S(dx3), xs, M=S_ * Cout, K=Cin)
+    close(dW3.view(S_ * Cout, Cin), W3.grad, 1e-3, sc(W3.grad), 'dW3')
+    dpq4 = S(dpq.view(1, S_ * 2 * R, N, V))
+    dxbar, _ = ops.conv(dpq4, K=S_ * 2 * R, w=t(W12), bias=None, M=Cin, wmode=1)
+    dx, _ = ops.conv(S(dx3), K=S_ * Cout, w=t(W3), bias=None, M=Cin, wmode=1, bcast=dxbar.view(Cin, N, V),
+                     bcast_scale=1.0 / T)
+    close(dx, x.grad, 1e-3, sc(x.grad), 'dx')
+    dW12 = ops.wgrad(dpq4, S(xb.view(1, Cin, N, V)), M=S_ * 2 * R, K=Cin)
+    close(dW12.view(S_ * 2 * R, Cin), W12.grad, 1e-3, sc(W12.grad), 'dW12')
+
+
+def test_elementwise_kernels():
+    from tam_gcn_amd import ops
+    from tam_gcn_amd.ops import S
+    N, C_, T, V = 2, 20, 13, 20
+    d = dev()
+    y, o, r = rnd((N, C_, T, V), 1), rnd((N, C_, T, V), 2), rnd((N, C_, T, V), 3)
+    cy, co = rnd((3, C_), 4), rnd((3, C_), 5)
+    ap = lambda c, z: c[0][None, :, None, None] * z + c[2][None, :, None, None]
+    g = torch.relu(ap(cy, y) + torch.tanh(ap(co, o)) + r)
+    gg = ops.gcn_tail_fwd(S(y.to(d), coef=cy.to(d)), S(o.to(d), coef=co.to(d)), S(r.to(d)))
+    close(gg, g, 1e-5, 1e-5)
+    dg = rnd((N, C_, T, V), 6)
+    dsum, doz, part = ops.gcn_tail_bwd(dg.to(d), gg, S(o.to(d), coef=co.to(d)))
+    e_dsum = dg * (g > 0)
+    e_doz = e_dsum * (1 - torch.tanh(ap(co, o)) ** 2)
+    close(dsum, e_dsum, 1e-5, 1e-5); close(doz, e_doz, 1e-4, 1e-5)
+    close(part[0].sum(-1), e_doz.sum((0, 2, 3)), 1e-3, 1e-3)
+    close(part[1].sum(-1), (e_doz * o).sum((0, 2, 3)), 1e-3, 1e-3)
+    # max-pool fwd/bwd, stride 1 and 2, vs autograd
+    for s in (1, 2):
+        h = rnd((N, C_, T, V), 7).requires_grad_(True)
+        ch = rnd((3, C_), 8)
+        a = torch.relu(ap(ch, h))
+        mp = F.max_pool2d(a, (3, 1), (s, 1), (1, 0))
+        cot = rnd(tuple(mp.shape), 9)
+        (mp * cot).sum().backward()
+        # reference gradient wrt the BN output (before ReLU): autograd through relu
+        hb = ap(ch, h.detach()).requires_grad_(True)
+        (F.max_pool2d(torch.relu(hb), (3, 1), (s, 1), (1, 0)) * cot).sum().backward()
+        T2 = mp.shape[2]
+        yb = torch.zeros(N, C_ + 4, T2, V, device=d)
+        src = S(h.detach().to(d), coef=ch.to(d), act=1)
+        part = ops.maxpool_fwd(src, C_, s, yb, 4, stats=True)
+        close(yb[:, 4:], mp, 1e-5, 1e-6)
+        close(part[0, 4:].sum(-1), mp.sum((0, 2, 3)), 1e-3, 1e-3)
+        dd = torch.zeros(N, C_ + 2, T, V, device=d)
+        bp = ops.maxpool_bwd(S(cot.to(d)), src, C_, s, dd, 2)
+        close(dd[:, 2:], hb.grad, 1e-5, 1e-6, f'maxpool bwd s={s}')
+        close(bp[1, 2:].sum(-1), (hb.grad * h.detach()).sum((0, 2, 3)), 1e-3, 1e-3)

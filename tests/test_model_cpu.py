@@ -93,6 +93,9 @@ def test_oracle_model_vs_golden(case, golden_models):
         assert abs(g[1] - bd[i][1]) <= 1e-4 * abs(bd[i][1]) + 1e-6, k
     with torch.no_grad():
         sde = {k: v.detach() for k, v in sd.items()}
+        for k in list(sde):
+            if 'running_' in k:
+                sde[k] = torch.from_numpy(gold[f'{tag}/evalbuf/{k}'])
         le = O.model_forward(x.detach(), sde, margs['num_point'], training=False)
         f1, _ = O.model_extract_feature(x.detach(), sde, margs['num_point'], training=False)
     np.testing.assert_allclose(le.numpy(), gold[f'{tag}/logits_eval'], rtol=1e-3, atol=1e-3)
