@@ -70,8 +70,8 @@ int         tamgcn_ctrgc_lds_bytes(int S, int V, int R);
  *        + sum_{k,j} W(m,k,j) * src(n, k, t*stride + j*dil - pad, v)
  *        + bcast[m, n, v]*bcast_scale + add1[...] + add2[...]
  *   then  y *= (mask_src > 0)  if mask is given,
- *   and per-channel partial sums  (sum y, sum y*aux)  -> stats_part
- *   (aux = y itself when aux is NULL: the train-mode BatchNorm moments).
+ *   and per-channel partial sums  (sum y, sum y*(aux - aux_center))  -> stats_part
+ *   (aux = y itself, uncentred, when aux is NULL: the train-mode BatchNorm moments).
  * ---------------------------------------------------------------------- */
 typedef struct tamgcn_conv_desc {
     tamgcn_src src;                 /* (N, src.ctot, T_in, V); uses K channels from src.coff */
@@ -92,6 +92,7 @@ typedef struct tamgcn_conv_desc {
     float bcast_scale;
     const tamgcn_src* mask;         /* optional, geometry of y: y *= (value > 0) */
     const float* aux;               /* optional, geometry (N, auxctot, T_y, V) at auxcoff */
+    const float* aux_center;        /* [auxctot] per-channel value subtracted from aux (the BN batch mean) */
     int auxctot, auxcoff;
     float* stats_part;              /* optional [2][stats_ctot][nparts] written at channel stats_coff+m */
     int stats_ctot, stats_coff;
@@ -133,7 +134,8 @@ int tamgcn_bn_fwd_finalize(const float* part, int part_ctot, int part_coff, int 
                            float momentum, float eps, int training,
                            float* coef, float* save, int coef_ctot, int coef_coff, int C, void* stream);
 
-/* part = [2][part_ctot][nparts] partial sums of (dz, dz*x_pre) per channel.
+/* part = [2][part_ctot][nparts] partial sums of (dz, dz*(x_pre - mean)) per channel; every backward
+ * reducer below centres by the saved batch mean (save[0]) so that dgamma has no cancellation.
  * Produces dgamma, dbeta, the bias gradient of the conv that fed the BN (optional) and the
  * backward-apply coefficients  d x_pre = c1*dz + c2*x_pre + c0  (train: full BN backward;
  * eval: c1 = gamma*invstd, c2 = c0 = 0). */
@@ -193,12 +195,13 @@ int tamgcn_ew_nparts(int N, int C, int T, int V);
  *   res = 0 | x | coef-applied d_pre  (res may be NULL). */
 int tamgcn_gcn_tail_fwd(const tamgcn_src* y, const tamgcn_src* o, const tamgcn_src* res,
                         int N, int C, int T, int V, float* g, void* stream);
-/* dsum = dg*(g>0); doz = dsum*(1-tanh(obn)^2); partials (sum doz, sum doz*o_pre) */
-int tamgcn_gcn_tail_bwd(const float* dg, const float* g, const tamgcn_src* o,
+/* dsum = dg*(g>0); doz = dsum*(1-tanh(obn)^2); partials (sum doz, sum doz*(o_pre - o_save[c])) */
+int tamgcn_gcn_tail_bwd(const float* dg, const float* g, const tamgcn_src* o, const float* o_save,
                         int N, int C, int T, int V, float* dsum, float* doz, float* part, void* stream);
 /* dyb = dsum - ddiff ; dres = dsum + ddiff (dres optional);
  * part[0..1] = (sum dyb, sum dyb*y_pre); part[2..3] = (sum dres, sum dres*r_pre) if r_pre given */
-int tamgcn_gcn_mid_bwd(const float* dsum, const float* ddiff, const float* y_pre, const float* r_pre,
+int tamgcn_gcn_mid_bwd(const float* dsum, const float* ddiff, const float* y_pre, const float* y_save,
+                       const float* r_pre, const float* r_save,
                        int N, int C, int T, int V, float* dyb, float* dres, float* part, void* stream);
 
 /* MaxPool2d((3,1), stride (s,1), pad (1,0)) over the prologue value (models/ctrgcn.py:117),
@@ -208,7 +211,7 @@ int tamgcn_maxpool_fwd(const tamgcn_src* src, int N, int C, int T_in, int V, int
 /* d src_value routed to the first arg-max of each window, times relu mask (value > 0);
  * gy goes through its own prologue; result written at channel dcoff of d (N, dctot, T_in, V),
  * partials (sum d, sum d*src.x1) at the same channel of [2][dctot][nparts]. */
-int tamgcn_maxpool_bwd(const tamgcn_src* gy, const tamgcn_src* src, int N, int C, int T_in, int T_out, int V,
+int tamgcn_maxpool_bwd(const tamgcn_src* gy, const tamgcn_src* src, const float* src_save, int N, int C, int T_in, int T_out, int V,
                        int stride, float* d, int dctot, int dcoff, float* part, void* stream);
 
 /* out = act( a + res ), a = prologue value of `a`, res = NULL | src (identity or coef-applied
@@ -217,7 +220,8 @@ int tamgcn_add_act_fwd(const tamgcn_src* a, const tamgcn_src* res, int relu,
                        int N, int C, int T, int V, float* out, void* stream);
 /* dz = dout * (out>0) (relu=1; dz may be NULL when relu=0 and only sums are wanted);
  * part[0..1] = (sum dz, sum dz*a_pre), part[2..3] = (sum dz, sum dz*r_pre) if r_pre given. */
-int tamgcn_add_act_bwd(const float* dout, const float* out, int relu, const float* a_pre, const float* r_pre,
+int tamgcn_add_act_bwd(const float* dout, const float* out, int relu, const float* a_pre, const float* a_save,
+                       const float* r_pre, const float* r_save,
                        int N, int C, int T, int V, float* dz, float* part, void* stream);
 
 /* y = prologue value (materialise a src; used by stand-alone modules and tests) */

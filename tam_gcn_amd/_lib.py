@@ -27,7 +27,7 @@ class ConvDesc(C.Structure):
                 ('T_out', C.c_int), ('T_y', C.c_int), ('ostride', C.c_int),
                 ('add1', C.c_void_p), ('add2', C.c_void_p), ('bcast', C.c_void_p), ('bcast_scale', C.c_float),
                 ('mask', C.POINTER(Src)),
-                ('aux', C.c_void_p), ('auxctot', C.c_int), ('auxcoff', C.c_int),
+                ('aux', C.c_void_p), ('aux_center', C.c_void_p), ('auxctot', C.c_int), ('auxcoff', C.c_int),
                 ('stats_part', C.c_void_p), ('stats_ctot', C.c_int), ('stats_coff', C.c_int)]
 
 
@@ -65,12 +65,12 @@ SIGNATURES = {
     'tamgcn_ctrgc_bwd_de': (_i, [C.POINTER(CtrgcDesc), _SP, _p, _p, _p, _p, _p, _p]),
     'tamgcn_ew_nparts': (_i, [_i, _i, _i, _i]),
     'tamgcn_gcn_tail_fwd': (_i, [_SP, _SP, _SP, _i, _i, _i, _i, _p, _p]),
-    'tamgcn_gcn_tail_bwd': (_i, [_p, _p, _SP, _i, _i, _i, _i, _p, _p, _p, _p]),
-    'tamgcn_gcn_mid_bwd': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
+    'tamgcn_gcn_tail_bwd': (_i, [_p, _p, _SP, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
+    'tamgcn_gcn_mid_bwd': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
     'tamgcn_maxpool_fwd': (_i, [_SP, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _p]),
-    'tamgcn_maxpool_bwd': (_i, [_SP, _SP, _i, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p]),
+    'tamgcn_maxpool_bwd': (_i, [_SP, _SP, _p, _i, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p]),
     'tamgcn_add_act_fwd': (_i, [_SP, _SP, _i, _i, _i, _i, _i, _p, _p]),
-    'tamgcn_add_act_bwd': (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
+    'tamgcn_add_act_bwd': (_i, [_p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
     'tamgcn_apply': (_i, [_SP, _i, _i, _i, _i, _p, _i, _i, _p]),
 }
 

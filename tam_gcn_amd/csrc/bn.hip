@@ -61,11 +61,11 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(
     const float* p2 = part + ((long long)1 * part_ctot + part_coff + c) * nparts;
     double s1 = 0.0, s2 = 0.0;
     for (int i = lane; i < nparts; i += 64) { s1 += (double)p1[i]; s2 += (double)p2[i]; }
-    s1 = wave_sum64d(s1); s2 = wave_sum64d(s2);          // s1 = sum dz, s2 = sum dz * x_pre
+    s1 = wave_sum64d(s1); s2 = wave_sum64d(s2);          // s1 = sum dz, s2 = sum dz * (x_pre - mean)
     if (lane == 0) {
         double mean = (double)save[save_coff + c], invstd = (double)save[save_ctot + save_coff + c];
         double g = gamma ? (double)gamma[c] : 1.0;
-        double dg = (s2 - mean * s1) * invstd;            // sum dz * xhat
+        double dg = s2 * invstd;                          // sum dz * xhat (producers centre by the saved mean)
         double a = g * invstd;
         double c1 = a, c2 = 0.0, c0 = 0.0;
         if (training) {

@@ -33,7 +33,7 @@ struct ConvArgs {
     float* y; int yctot, ycoff, T_out, T_y, ostride;
     const float* add1; const float* add2; const float* bcast; float bcast_scale;
     SrcDev mask; int has_mask;
-    const float* aux; int auxctot, auxcoff;
+    const float* aux; const float* aux_center; int auxctot, auxcoff;
     float* stats_part; int stats_ctot, stats_coff, nparts;
     // tiling (host chosen)
     int BT;        // output frames per block
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel(const ConvArgs a) {
                 a.y[idx] = val;
                 if (a.stats_part) {
                     float x2 = val;
-                    if (a.aux) x2 = a.aux[(((long long)n * a.auxctot + a.auxcoff + m) * a.T_y + t) * V + vv[c]];
+                    if (a.aux) x2 = a.aux[(((long long)n * a.auxctot + a.auxcoff + m) * a.T_y + t) * V + vv[c]] - a.aux_center[a.auxcoff + m];
                     s1[mt][r] += val;
                     s2[mt][r] = fmaf(val, x2, s2[mt][r]);
                 }
@@ -260,7 +260,8 @@ extern "C" int tamgcn_conv(const tamgcn_conv_desc* d, void* stream) {
     a.y = d->y; a.yctot = d->yctot; a.ycoff = d->ycoff; a.T_out = d->T_out; a.T_y = d->T_y; a.ostride = d->ostride;
     a.add1 = d->add1; a.add2 = d->add2; a.bcast = d->bcast; a.bcast_scale = d->bcast_scale;
     a.has_mask = d->mask != nullptr; a.mask = d->mask ? make_src(*d->mask) : null_src();
-    a.aux = d->aux; a.auxctot = d->auxctot; a.auxcoff = d->auxcoff;
+    a.aux = d->aux; a.aux_center = d->aux_center; a.auxctot = d->auxctot; a.auxcoff = d->auxcoff;
+    TG_CHECK(!d->aux || d->aux_center, "tamgcn_conv: aux needs aux_center");
     a.stats_part = d->stats_part; a.stats_ctot = d->stats_ctot; a.stats_coff = d->stats_coff;
     a.nparts = d->N * p.ntt;
     a.BT = p.BT; a.CW = p.CW; a.TIN = p.TIN; a.lstride = p.lstride; a.sB = p.sB; a.LB = p.LB; a.pitchB = p.pitchB;

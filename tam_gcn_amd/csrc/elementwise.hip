@@ -38,12 +38,13 @@ __global__ __launch_bounds__(EW_THREADS) void gcn_tail_fwd_kernel(SrcDev y, SrcD
     }
 }
 
-__global__ __launch_bounds__(EW_THREADS) void gcn_tail_bwd_kernel(const float* dg, const float* g, SrcDev o,
+__global__ __launch_bounds__(EW_THREADS) void gcn_tail_bwd_kernel(const float* dg, const float* g, SrcDev o, const float* o_save,
                                                                   int C, int L, int N, float* dsum, float* doz, float* part) {
     const int c = blockIdx.x, n = blockIdx.y;
     const long long b = ((long long)n * C + c) * L;
     const long long bo = ((long long)n * o.ctot + o.coff + c) * L;
     float s[2] = {0.f, 0.f};
+    const float mu = o_save[o.coff + c];
     for (int i = threadIdx.x; i < L; i += EW_THREADS) {
         float d = g[b + i] > 0.f ? dg[b + i] : 0.f;
         float off = tanhf(src_value(o, bo + i, o.coff + c));
@@ -51,25 +52,26 @@ __global__ __launch_bounds__(EW_THREADS) void gcn_tail_bwd_kernel(const float* d
         dsum[b + i] = d;
         doz[b + i] = dz;
         s[0] += dz;
-        s[1] = fmaf(dz, o.x1[bo + i], s[1]);
+        s[1] = fmaf(dz, o.x1[bo + i] - mu, s[1]);
     }
     block_store_sums(s, 2, part, C, N, c, n);
 }
 
-__global__ __launch_bounds__(EW_THREADS) void gcn_mid_bwd_kernel(const float* dsum, const float* ddiff, const float* y_pre,
-                                                                 const float* r_pre, int C, int L, int N,
+__global__ __launch_bounds__(EW_THREADS) void gcn_mid_bwd_kernel(const float* dsum, const float* ddiff, const float* y_pre, const float* y_save,
+                                                                 const float* r_pre, const float* r_save, int C, int L, int N,
                                                                  float* dyb, float* dres, float* part) {
     const int c = blockIdx.x, n = blockIdx.y;
     const long long b = ((long long)n * C + c) * L;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
+    const float muy = y_save[c], mur = r_pre ? r_save[c] : 0.f;
     for (int i = threadIdx.x; i < L; i += EW_THREADS) {
         float d = dsum[b + i], dd = ddiff[b + i];
         float a = d - dd, r = d + dd;
         dyb[b + i] = a;
         s[0] += a;
-        s[1] = fmaf(a, y_pre[b + i], s[1]);
+        s[1] = fmaf(a, y_pre[b + i] - muy, s[1]);
         if (dres) dres[b + i] = r;
-        if (r_pre) { s[2] += r; s[3] = fmaf(r, r_pre[b + i], s[3]); }
+        if (r_pre) { s[2] += r; s[3] = fmaf(r, r_pre[b + i] - mur, s[3]); }
     }
     block_store_sums(s, r_pre ? 4 : 2, part, C, N, c, n);
 }
@@ -95,13 +97,14 @@ __global__ __launch_bounds__(EW_THREADS) void maxpool_fwd_kernel(SrcDev src, int
     if (part) block_store_sums(s, 2, part, yctot, N, ycoff + c, n);
 }
 
-__global__ __launch_bounds__(EW_THREADS) void maxpool_bwd_kernel(SrcDev gy, SrcDev src, int C, int T_in, int T_out, int V,
+__global__ __launch_bounds__(EW_THREADS) void maxpool_bwd_kernel(SrcDev gy, SrcDev src, const float* src_save, int C, int T_in, int T_out, int V,
                                                                  int stride, float* d, int dctot, int dcoff, int N, float* part) {
     const int c = blockIdx.x, n = blockIdx.y;
     const long long bs = ((long long)n * src.ctot + src.coff + c) * T_in * V;
     const long long bg = ((long long)n * gy.ctot + gy.coff + c) * T_out * V;
     float* dp = d + ((long long)n * dctot + dcoff + c) * T_in * V;
     float s[2] = {0.f, 0.f};
+    const float mu = src_save[src.coff + c];
     for (int i = threadIdx.x; i < T_in * V; i += EW_THREADS) {
         int th = i / V, v = i - th * V;
         float x0 = src_value(src, bs + i, src.coff + c);
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(EW_THREADS) void maxpool_bwd_kernel(SrcDev gy, SrcD
         }
         dp[i] = grad;
         s[0] += grad;
-        s[1] = fmaf(grad, src.x1[bs + i], s[1]);
+        s[1] = fmaf(grad, src.x1[bs + i] - mu, s[1]);
     }
     if (part) block_store_sums(s, 2, part, dctot, N, dcoff + c, n);
 }
@@ -144,18 +147,20 @@ __global__ __launch_bounds__(EW_THREADS) void add_act_fwd_kernel(SrcDev a, SrcDe
 }
 
 __global__ __launch_bounds__(EW_THREADS) void add_act_bwd_kernel(const float* dout, const float* out, int relu,
-                                                                 const float* a_pre, const float* r_pre,
+                                                                 const float* a_pre, const float* a_save,
+                                                                 const float* r_pre, const float* r_save,
                                                                  int C, int L, int N, float* dz, float* part) {
     const int c = blockIdx.x, n = blockIdx.y;
     const long long b = ((long long)n * C + c) * L;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
+    const float mua = a_pre ? a_save[c] : 0.f, mur = r_pre ? r_save[c] : 0.f;
     for (int i = threadIdx.x; i < L; i += EW_THREADS) {
         float d = dout[b + i];
         if (relu && !(out[b + i] > 0.f)) d = 0.f;
         if (dz) dz[b + i] = d;
         s[0] += d;
-        if (a_pre) s[1] = fmaf(d, a_pre[b + i], s[1]);
-        if (r_pre) { s[2] += d; s[3] = fmaf(d, r_pre[b + i], s[3]); }
+        if (a_pre) s[1] = fmaf(d, a_pre[b + i] - mua, s[1]);
+        if (r_pre) { s[2] += d; s[3] = fmaf(d, r_pre[b + i] - mur, s[3]); }
     }
     block_store_sums(s, r_pre ? 4 : 2, part, C, N, c, n);
 }
@@ -194,20 +199,21 @@ extern "C" int tamgcn_gcn_tail_fwd(const tamgcn_src* y, const tamgcn_src* o, con
     return 0;
 }
 
-extern "C" int tamgcn_gcn_tail_bwd(const float* dg, const float* g, const tamgcn_src* o,
+extern "C" int tamgcn_gcn_tail_bwd(const float* dg, const float* g, const tamgcn_src* o, const float* o_save,
                                    int N, int C, int T, int V, float* dsum, float* doz, float* part, void* stream) {
-    TG_CHECK(dg && g && o && o->x1 && dsum && doz && part && grid_ok(N, C), "tamgcn_gcn_tail_bwd: bad args");
+    TG_CHECK(dg && g && o && o->x1 && o_save && dsum && doz && part && grid_ok(N, C), "tamgcn_gcn_tail_bwd: bad args");
     hipLaunchKernelGGL(gcn_tail_bwd_kernel, dim3(C, N), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                       dg, g, make_src(*o), C, T * V, N, dsum, doz, part);
+                       dg, g, make_src(*o), o_save, C, T * V, N, dsum, doz, part);
     TG_LAUNCH_CHECK("tamgcn_gcn_tail_bwd");
     return 0;
 }
 
-extern "C" int tamgcn_gcn_mid_bwd(const float* dsum, const float* ddiff, const float* y_pre, const float* r_pre,
+extern "C" int tamgcn_gcn_mid_bwd(const float* dsum, const float* ddiff, const float* y_pre, const float* y_save,
+                                  const float* r_pre, const float* r_save,
                                   int N, int C, int T, int V, float* dyb, float* dres, float* part, void* stream) {
-    TG_CHECK(dsum && ddiff && y_pre && dyb && part && grid_ok(N, C), "tamgcn_gcn_mid_bwd: bad args");
+    TG_CHECK(dsum && ddiff && y_pre && y_save && dyb && part && grid_ok(N, C) && (!r_pre || r_save), "tamgcn_gcn_mid_bwd: bad args");
     hipLaunchKernelGGL(gcn_mid_bwd_kernel, dim3(C, N), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                       dsum, ddiff, y_pre, r_pre, C, T * V, N, dyb, dres, part);
+                       dsum, ddiff, y_pre, y_save, r_pre, r_save, C, T * V, N, dyb, dres, part);
     TG_LAUNCH_CHECK("tamgcn_gcn_mid_bwd");
     return 0;
 }
@@ -222,11 +228,11 @@ extern "C" int tamgcn_maxpool_fwd(const tamgcn_src* src, int N, int C, int T_in,
     return 0;
 }
 
-extern "C" int tamgcn_maxpool_bwd(const tamgcn_src* gy, const tamgcn_src* src, int N, int C, int T_in, int T_out, int V,
+extern "C" int tamgcn_maxpool_bwd(const tamgcn_src* gy, const tamgcn_src* src, const float* src_save, int N, int C, int T_in, int T_out, int V,
                                   int stride, float* d, int dctot, int dcoff, float* part, void* stream) {
-    TG_CHECK(gy && src && gy->x1 && src->x1 && d && grid_ok(N, C) && stride >= 1, "tamgcn_maxpool_bwd: bad args");
+    TG_CHECK(gy && src && gy->x1 && src->x1 && src_save && d && grid_ok(N, C) && stride >= 1, "tamgcn_maxpool_bwd: bad args");
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(C, N), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                       make_src(*gy), make_src(*src), C, T_in, T_out, V, stride, d, dctot, dcoff, N, part);
+                       make_src(*gy), make_src(*src), src_save, C, T_in, T_out, V, stride, d, dctot, dcoff, N, part);
     TG_LAUNCH_CHECK("tamgcn_maxpool_bwd");
     return 0;
 }
@@ -240,11 +246,12 @@ extern "C" int tamgcn_add_act_fwd(const tamgcn_src* a, const tamgcn_src* res, in
     return 0;
 }
 
-extern "C" int tamgcn_add_act_bwd(const float* dout, const float* out, int relu, const float* a_pre, const float* r_pre,
+extern "C" int tamgcn_add_act_bwd(const float* dout, const float* out, int relu, const float* a_pre, const float* a_save,
+                                  const float* r_pre, const float* r_save,
                                   int N, int C, int T, int V, float* dz, float* part, void* stream) {
-    TG_CHECK(dout && part && grid_ok(N, C) && (!relu || out), "tamgcn_add_act_bwd: bad args");
+    TG_CHECK(dout && part && grid_ok(N, C) && (!relu || out) && (!a_pre || a_save) && (!r_pre || r_save), "tamgcn_add_act_bwd: bad args");
     hipLaunchKernelGGL(add_act_bwd_kernel, dim3(C, N), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                       dout, out, relu, a_pre, r_pre, C, T * V, N, dz, part);
+                       dout, out, relu, a_pre, a_save, r_pre, r_save, C, T * V, N, dz, part);
     TG_LAUNCH_CHECK("tamgcn_add_act_bwd");
     return 0;
 }

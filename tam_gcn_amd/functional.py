@@ -100,7 +100,7 @@ def gcn_backward(P, sv, dg, need_dx=True, extra_dx=None):
     count = N * T * V
     G = {}
     # tail: relu, tanh(BN(offset conv))
-    dsum, doz, part_o = ops.gcn_tail_bwd(dg, g, S(o_pre, coef=sv['coef_o']))
+    dsum, doz, part_o = ops.gcn_tail_bwd(dg, g, S(o_pre, coef=sv['coef_o']), sv['save_o'])
     coefb_o = torch.empty(3, Cout, device=x.device)
     G['bno.w'], G['bno.b'], G['bo'] = P.bno.bwd(part_o, 0, count, sv['save_o'], 0, training, coefb_o, 0, want_dbias=True)
     gyo = S(doz, o_pre, coefb_o)
@@ -112,8 +112,8 @@ def gcn_backward(P, sv, dg, need_dx=True, extra_dx=None):
     else:
         diff = S(y_pre, None, sv['coef_diff'])
     G['Wo'] = ops.wgrad(gyo, diff, M=Cout, K=Cout)
-    dyb, dres, part2 = ops.gcn_mid_bwd(dsum, ddiff, y_pre, d_pre if P.mode == 'conv' else None,
-                                       want_dres=P.mode != 'zero')
+    dyb, dres, part2 = ops.gcn_mid_bwd(dsum, ddiff, y_pre, sv['save_y'], d_pre if P.mode == 'conv' else None,
+                                       sv['save_d'], want_dres=P.mode != 'zero')
     coefb_y = torch.empty(3, Cout, device=x.device)
     G['bn.w'], G['bn.b'], _ = P.bn.bwd(part2, 0, count, sv['save_y'], 0, training, coefb_y, 0)
     dy = S(dyb, y_pre, coefb_y)
@@ -217,7 +217,7 @@ def tcn_backward(P, sv, dout, need_dg=True, need_dxres=True):
     cnt1, cnt2 = N * T * V, N * T2 * V
     Ch = (nb + 1) * Cb
     G = {}
-    dz, part = ops.add_act_bwd(dout, out, P.relu, cat_pre, r_pre, want_dz=bool(P.relu))
+    dz, part = ops.add_act_bwd(dout, out, P.relu, cat_pre, sv['save_c'], r_pre, sv['save_r'], want_dz=bool(P.relu))
     if dz is None:
         dz = dout
     coefb_c = torch.empty(3, Cout, device=g.device)
@@ -246,13 +246,15 @@ def tcn_backward(P, sv, dout, need_dg=True, need_dxres=True):
         pad = _tpad(k, d)
         _, hp = ops.conv(gcat(b * Cb), K=Cb, w=P.Wt[b], bias=None, M=Cb, KT=k, dil=d, stride=1,
                          pad=(k - 1) * d - pad, wmode=1, up=s, y=dh, ycoff=b * Cb, T_out=T,
-                         mask=S(h_pre, coef=sv['coef_h'], coff=b * Cb), aux=h_pre, auxcoff=b * Cb, stats=True)
+                         mask=S(h_pre, coef=sv['coef_h'], coff=b * Cb), aux=h_pre, aux_center=sv['save_h'], auxcoff=b * Cb,
+                         stats=True)
         G['Wt'].append(ops.wgrad(gcat(b * Cb), S(h_pre, coef=sv['coef_h'], coff=b * Cb, act=RELU), M=Cb, K=Cb,
                                  KT=k, dil=d, stride=s, pad=pad))
         dgam, dbet, dbias = P.bn_in[b].bwd(hp, b * Cb, cnt1, sv['save_h'], b * Cb, training, coefb_h, b * Cb, True)
         G['bn_in'].append((dgam, dbet))
         dbin.append(dbias)
-    hp = ops.maxpool_bwd(gcat(nb * Cb), S(h_pre, coef=sv['coef_h'], coff=nb * Cb, act=RELU), Cb, s, dh, nb * Cb)
+    hp = ops.maxpool_bwd(gcat(nb * Cb), S(h_pre, coef=sv['coef_h'], coff=nb * Cb, act=RELU), sv['save_h'], Cb, s, dh,
+                         nb * Cb)
     dgam, dbet, dbias = P.bn_in[nb].bwd(hp, nb * Cb, cnt1, sv['save_h'], nb * Cb, training, coefb_h, nb * Cb, True)
     G['bn_in'].append((dgam, dbet))
     dbin.append(dbias)
@@ -422,7 +424,7 @@ class ConvBNFn(torch.autograd.Function):
         dout = dout.contiguous()
         N, Cin, T, V = x.shape
         M, T2 = y_pre.shape[1], y_pre.shape[2]
-        _, part = ops.add_act_bwd(dout, None, 0, y_pre, None, want_dz=False)
+        _, part = ops.add_act_bwd(dout, None, 0, y_pre, save, None, None, want_dz=False)
         coefb = torch.empty(3, M, device=x.device)
         dgam, dbet, dbias = bn.bwd(part, 0, N * T2 * V, save, 0, training, coefb, 0, True)
         gy = S(dout, y_pre, coefb)

@@ -52,7 +52,7 @@ def empty(*shape, like):
 # ---------------------------------------------------------------------------
 def conv(src, K, w, bias, M, KT=1, dil=1, stride=1, pad=0, wmode=0, up=1,
          y=None, ycoff=0, T_out=None, T_y=None, ostride=1, add1=None, add2=None,
-         bcast=None, bcast_scale=0.0, mask=None, aux=None, auxcoff=0, stats=False):
+         bcast=None, bcast_scale=0.0, mask=None, aux=None, aux_center=None, auxcoff=0, stats=False):
     """y (N, yctot, T_y, V); returns (y, stats_part [2][yctot][nparts] or None)."""
     x = src.x1
     N, _, T_in, V = x.shape
@@ -78,7 +78,7 @@ def conv(src, K, w, bias, M, KT=1, dil=1, stride=1, pad=0, wmode=0, up=1,
         mc = mask.c()
         d.mask = C.pointer(mc)
     if aux is not None:
-        d.aux, d.auxctot, d.auxcoff = _ptr(aux), aux.shape[1], auxcoff
+        d.aux, d.aux_center, d.auxctot, d.auxcoff = _ptr(aux), _ptr(aux_center), aux.shape[1], auxcoff
     part = None
     lib = _lib_()
     if stats:
@@ -205,22 +205,22 @@ def gcn_tail_fwd(y, o, res):
     return g
 
 
-def gcn_tail_bwd(dg, g, o):
+def gcn_tail_bwd(dg, g, o, o_save):
     N, Cc, T, V = g.shape
     dsum, doz = torch.empty_like(g), torch.empty_like(g)
     part = empty(2, Cc, N, like=g)
     oc = o.c()
-    _lib.check(_lib_().tamgcn_gcn_tail_bwd(_ptr(dg), _ptr(g), C.byref(oc), N, Cc, T, V, _ptr(dsum), _ptr(doz),
+    _lib.check(_lib_().tamgcn_gcn_tail_bwd(_ptr(dg), _ptr(g), C.byref(oc), _ptr(o_save), N, Cc, T, V, _ptr(dsum), _ptr(doz),
                                            _ptr(part), _stream()), 'tamgcn_gcn_tail_bwd')
     return dsum, doz, part
 
 
-def gcn_mid_bwd(dsum, ddiff, y_pre, r_pre, want_dres):
+def gcn_mid_bwd(dsum, ddiff, y_pre, y_save, r_pre, r_save, want_dres):
     N, Cc, T, V = dsum.shape
     dyb = torch.empty_like(dsum)
     dres = torch.empty_like(dsum) if want_dres else None
     part = empty(4 if r_pre is not None else 2, Cc, N, like=dsum)
-    _lib.check(_lib_().tamgcn_gcn_mid_bwd(_ptr(dsum), _ptr(ddiff), _ptr(y_pre), _ptr(r_pre), N, Cc, T, V,
+    _lib.check(_lib_().tamgcn_gcn_mid_bwd(_ptr(dsum), _ptr(ddiff), _ptr(y_pre), _ptr(y_save), _ptr(r_pre), _ptr(r_save), N, Cc, T, V,
                                           _ptr(dyb), _ptr(dres), _ptr(part), _stream()), 'tamgcn_gcn_mid_bwd')
     return dyb, dres, part
 
@@ -235,12 +235,12 @@ def maxpool_fwd(src, C_, stride, y, ycoff, stats):
     return part
 
 
-def maxpool_bwd(gy, src, C_, stride, d, dcoff):
+def maxpool_bwd(gy, src, src_save, C_, stride, d, dcoff):
     N, _, T_in, V = src.x1.shape
     T_out = gy.x1.shape[2]
     part = empty(2, d.shape[1], N, like=d)
     gc, sc = gy.c(), src.c()
-    _lib.check(_lib_().tamgcn_maxpool_bwd(C.byref(gc), C.byref(sc), N, C_, T_in, T_out, V, stride, _ptr(d),
+    _lib.check(_lib_().tamgcn_maxpool_bwd(C.byref(gc), C.byref(sc), _ptr(src_save), N, C_, T_in, T_out, V, stride, _ptr(d),
                                           d.shape[1], dcoff, _ptr(part), _stream()), 'tamgcn_maxpool_bwd')
     return part
 
@@ -255,11 +255,11 @@ def add_act_fwd(a, res, relu, C_):
     return out
 
 
-def add_act_bwd(dout, out, relu, a_pre, r_pre, want_dz):
+def add_act_bwd(dout, out, relu, a_pre, a_save, r_pre, r_save, want_dz):
     N, Cc, T, V = dout.shape
     dz = torch.empty_like(dout) if want_dz else None
     part = empty(4 if r_pre is not None else 2, Cc, N, like=dout)
-    _lib.check(_lib_().tamgcn_add_act_bwd(_ptr(dout), _ptr(out), int(relu), _ptr(a_pre), _ptr(r_pre), N, Cc, T, V,
+    _lib.check(_lib_().tamgcn_add_act_bwd(_ptr(dout), _ptr(out), int(relu), _ptr(a_pre), _ptr(a_save), _ptr(r_pre), _ptr(r_save), N, Cc, T, V,
                                           _ptr(dz), _ptr(part), _stream()), 'tamgcn_add_act_bwd')
     return dz, part
 

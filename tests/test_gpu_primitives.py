@@ -85,7 +85,7 @@ def test_conv_prologue_slices_mask_aux():
     aux = rnd((N, 64, T, V), 7)
     yg, part = ops.conv(S(x1.to(dev()), x2.to(dev()), coef.to(dev()), coff=16, act=1), K=16, w=w.to(dev()), bias=None,
                         M=16, KT=5, pad=2, y=y, ycoff=32, add1=add1.to(dev()), mask=S(msk.to(dev()), coff=32),
-                        aux=aux.to(dev()), auxcoff=32, stats=True)
+                        aux=aux.to(dev()), aux_center=torch.zeros(64, device=dev()), auxcoff=32, stats=True)
     exp = (ref + add1[:, 32:48]) * (msk[:, 32:48] > 0)
     close(yg[:, 32:48], exp, 1e-4, 1e-4)
     assert float(yg[:, :32].min()) == 7.0 and float(yg[:, 48:].max()) == 7.0
@@ -118,7 +118,7 @@ def test_bn_finalize_fwd_bwd():
     close(rmd, rm, 1e-5, 1e-6); close(rvd, rv, 1e-5, 1e-6)
     assert int(nbt) == 1
     cd = cot.to(d)
-    _, bpart = ops.add_act_bwd(cd, None, 0, xd, None, want_dz=False)
+    _, bpart = ops.add_act_bwd(cd, None, 0, xd, save, None, None, want_dz=False)
     coefb = torch.empty(3, C_, device=d)
     dg = torch.empty(C_, device=d); db = torch.empty(C_, device=d); dbias = torch.empty(C_, device=d)
     ops.bn_bwd_finalize(bpart, 0, N * T * V, g.detach().to(d), save, 0, True, dg, db, dbias, coefb, 0, C_)
@@ -203,12 +203,13 @@ def test_elementwise_kernels():
     gg = ops.gcn_tail_fwd(S(y.to(d), coef=cy.to(d)), S(o.to(d), coef=co.to(d)), S(r.to(d)))
     close(gg, g, 1e-5, 1e-5)
     dg = rnd((N, C_, T, V), 6)
-    dsum, doz, part = ops.gcn_tail_bwd(dg.to(d), gg, S(o.to(d), coef=co.to(d)))
+    osave = rnd((2, C_), 11).to(d)
+    dsum, doz, part = ops.gcn_tail_bwd(dg.to(d), gg, S(o.to(d), coef=co.to(d)), osave)
     e_dsum = dg * (g > 0)
     e_doz = e_dsum * (1 - torch.tanh(ap(co, o)) ** 2)
     close(dsum, e_dsum, 1e-5, 1e-5); close(doz, e_doz, 1e-4, 1e-5)
     close(part[0].sum(-1), e_doz.sum((0, 2, 3)), 1e-3, 1e-3)
-    close(part[1].sum(-1), (e_doz * o).sum((0, 2, 3)), 1e-3, 1e-3)
+    close(part[1].sum(-1), (e_doz * (o - osave[0].cpu()[None, :, None, None])).sum((0, 2, 3)), 1e-3, 1e-3)
     # max-pool fwd/bwd, stride 1 and 2, vs autograd
     for s in (1, 2):
         h = rnd((N, C_, T, V), 7).requires_grad_(True)
@@ -227,6 +228,7 @@ def test_elementwise_kernels():
         close(yb[:, 4:], mp, 1e-5, 1e-6)
         close(part[0, 4:].sum(-1), mp.sum((0, 2, 3)), 1e-3, 1e-3)
         dd = torch.zeros(N, C_ + 2, T, V, device=d)
-        bp = ops.maxpool_bwd(S(cot.to(d)), src, C_, s, dd, 2)
+        hsave = rnd((2, C_), 12).to(d)
+        bp = ops.maxpool_bwd(S(cot.to(d)), src, hsave, C_, s, dd, 2)
         close(dd[:, 2:], hb.grad, 1e-5, 1e-6, f'maxpool bwd s={s}')
-        close(bp[1, 2:].sum(-1), (hb.grad * h.detach()).sum((0, 2, 3)), 1e-3, 1e-3)
+        close(bp[1, 2:].sum(-1), (hb.grad * (h.detach() - hsave[0].cpu()[None, :, None, None])).sum((0, 2, 3)), 1e-3, 1e-3)
