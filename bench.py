@@ -266,6 +266,7 @@ def main():
         bucket.zero()
         loss = torch.nn.functional.cross_entropy(model(x), lab)
         loss.backward()
+        bucket.pack()
         loss_buf.copy_(loss.detach())
 
     def eager_step():

@@ -29,7 +29,7 @@ struct ConvArgs {
     const float* w; const float* bias;
     int M, KT, dil, stride, pad;
     long long ws_m, ws_k, ws_t, w_off;   // weight element strides for A[i][k][tap]
-    int up;
+    int up, wmode;
     float* y; int yctot, ycoff, T_out, T_y, ostride;
     const float* add1; const float* add2; const float* bcast; float bcast_scale;
     SrcDev mask; int has_mask;
@@ -44,6 +44,77 @@ struct ConvArgs {
     int LB;        // TIN*V
     int pitchB;    // LDS pitch of one channel row (== 16 mod 32)
 };
+
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[4][MAXCW], float* Ss, int n, int m0, int t0,
+                                              int ncols, int cw0, int mt_act, int c_act, const int (&tl)[MAXCW],
+                                              const int (&vv)[MAXCW], int j, int kq, int wave, int tid) {
+    const int V = a.V;
+    float s1[4][4], s2[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[mt][r] = 0.f; s2[mt][r] = 0.f; }
+
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        if (mt >= mt_act) continue;
+#pragma unroll
+        for (int c = 0; c < MAXCW; ++c) {
+            if (c >= c_act) continue;
+            int col = (cw0 + c) * 16 + j;
+            if (col >= ncols) continue;
+            int t = (t0 + tl[c]) * a.ostride;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int m = m0 + mt * 16 + kq * 4 + r;
+                if (m >= a.M) continue;
+                float val = acc[mt][c][r];
+                if (a.bias) val += a.bias[m];
+                long long idx = (((long long)n * a.yctot + a.ycoff + m) * a.T_y + t) * V + vv[c];
+                if (a.bcast) val = fmaf(a.bcast[((long long)m * a.N + n) * V + vv[c]], a.bcast_scale, val);
+                if (a.add1) val += a.add1[idx];
+                if (a.add2) val += a.add2[idx];
+                if (a.has_mask) {
+                    int mch = a.mask.coff + m;
+                    long long midx = (((long long)n * a.mask.ctot + mch) * a.T_y + t) * V + vv[c];
+                    if (!(src_value(a.mask, midx, mch) > 0.f)) val = 0.f;
+                }
+                a.y[idx] = val;
+                if (a.stats_part) {
+                    float x2 = val;
+                    if (a.aux) x2 = a.aux[(((long long)n * a.auxctot + a.auxcoff + m) * a.T_y + t) * V + vv[c]] - a.aux_center[a.auxcoff + m];
+                    s1[mt][r] += val;
+                    s2[mt][r] = fmaf(val, x2, s2[mt][r]);
+                }
+            }
+        }
+    }
+    if (a.stats_part) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float u1 = wave_sum16(s1[mt][r]);
+                float u2 = wave_sum16(s2[mt][r]);
+                if (j == 0) {
+                    int row = mt * 16 + kq * 4 + r;
+                    Ss[(0 * 4 + wave) * BM + row] = u1;
+                    Ss[(1 * 4 + wave) * BM + row] = u2;
+                }
+            }
+        __syncthreads();
+        if (tid < 2 * BM) {
+            int st = tid >> 6, row = tid & 63;
+            int m = m0 + row;
+            if (m < a.M) {
+                float tot = Ss[(st * 4 + 0) * BM + row] + Ss[(st * 4 + 1) * BM + row] +
+                            Ss[(st * 4 + 2) * BM + row] + Ss[(st * 4 + 3) * BM + row];
+                int part = n * gridDim.x + blockIdx.x;
+                a.stats_part[((long long)st * a.stats_ctot + a.stats_coff + m) * a.nparts + part] = tot;
+            }
+        }
+    }
+}
 
 __global__ __launch_bounds__(NTHREADS) void conv_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -137,22 +208,166 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel(const ConvArgs a) {
         }
     }
 
-    // ---- epilogue
-    float s1[4][4], s2[4][4];
+    conv_epilogue(a, acc, Ss, n, m0, t0, ncols, cw0, mt_act, c_act, tl, vv, j, kq, wave, tid);
+}
+
+// ---------------------------------------------------------------------------
+// Vectorised, software-pipelined variant (V % 4 == 0, K <= 1024): the next K chunk's
+// activation rows are fetched with 16-byte global loads into registers while the MFMAs of
+// the current chunk run; the BatchNorm-apply prologue is applied on the way into LDS from a
+// per-channel coefficient table staged once per workgroup.
+// ---------------------------------------------------------------------------
+template <int BKV, int MT, int CWT>
+__global__ __launch_bounds__(NTHREADS) void conv_kernel_vec(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int BKVP = BKV + 2;                      // pitch/2 odd: conflict-free A-fragment column reads
+    constexpr int BMT = MT * 16;                       // output channels per workgroup
+    constexpr int NPF = (BKV == 32) ? 10 : 8;          // float4 prefetch slots per thread (host checks the bound)
+    float* As = smem;                                  // [KT][BMT][BKVP]
+    float* Bs = As + ((a.KT * BMT * BKVP + 3) & ~3);   // [BKV][pitchB], 16-byte aligned
+    float* Ss = Bs + BKV * a.pitchB;                   // [2][4][64]
+    float* cf = Ss + 2 * 4 * BM;                       // [3][K]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int n = blockIdx.z, m0 = blockIdx.y * BMT, t0 = blockIdx.x * a.BT;
+    const int V = a.V;
+    const int bt = min(a.BT, a.T_out - t0);
+    const int ncols = bt * V;
+    const int cw0 = wave * CWT;
+
+    for (int e = tid; e < a.K; e += NTHREADS) {
+        int ch = a.src.coff + e;
+        cf[e] = a.src.coef ? a.src.coef[ch] : 1.f;
+        cf[a.K + e] = (a.src.coef && a.src.x2) ? a.src.coef[a.src.ctot + ch] : 0.f;
+        cf[2 * a.K + e] = a.src.coef ? a.src.coef[2 * a.src.ctot + ch] : 0.f;
+    }
+
+    int boff[CWT], tl[CWT], vv[CWT];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int c = 0; c < CWT; ++c) {
+        int col = (cw0 + c) * 16 + j;
+        if (col < ncols) { tl[c] = col / V; vv[c] = col - tl[c] * V; boff[c] = tl[c] * a.sB * V + vv[c]; }
+        else { tl[c] = 0; vv[c] = 0; boff[c] = 0; }       // padding tile: reads in-bounds data, never stored
+    }
+    f32x4 acc[MT][CWT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int c = 0; c < CWT; ++c) acc[mt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // per-thread prefetch descriptors (identical for every K chunk)
+    const int tin0 = t0 * a.stride - a.pad;
+    const long long chan_stride = (long long)a.T_in * V;
+    const int LB4 = a.LB >> 2;
+    const int nvec = BKV * LB4;
+    int p_lds[NPF], p_kk[NPF];
+    long long p_g[NPF];
+    bool p_ok[NPF];
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+        int e = tid + i * NTHREADS;
+        int kk = e / LB4, c4 = e - kk * LB4;
+        int pos = c4 << 2;
+        int slot = pos / V, v = pos - slot * V;
+        int th = tin0 + slot * a.lstride;
+        bool ok = e < nvec && th >= 0;
+        if (a.up > 1) { ok = ok && (th % a.up == 0); th /= a.up; }
+        ok = ok && th < a.T_in;
+        p_ok[i] = ok;
+        p_kk[i] = e < nvec ? kk : -1;
+        p_lds[i] = kk * a.pitchB + pos;
+        p_g[i] = (long long)n * a.src.ctot * chan_stride + (long long)(a.src.coff + kk) * chan_stride + (long long)th * V + v;
+    }
+    float4 r1[NPF], r2[NPF];
+    const bool has2 = a.src.x2 != nullptr;
+    auto prefetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            r1[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            r2[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p_ok[i] && k0 + p_kk[i] < a.K) {
+                long long g = p_g[i] + (long long)k0 * chan_stride;
+                r1[i] = *reinterpret_cast<const float4*>(a.src.x1 + g);
+                if (has2) r2[i] = *reinterpret_cast<const float4*>(a.src.x2 + g);
+            }
+        }
+    };
+    prefetch(0);
+    __syncthreads();                                   // cf table visible
+
+    const float* arow = As + j * BKVP + kq;
+    for (int k0 = 0; k0 < a.K; k0 += BKV) {
+        __syncthreads();                               // previous chunk's MFMAs done with As/Bs
+        const int nA = a.KT * BMT * BKV;
+        if (a.wmode == 0) {                            // weight rows contiguous along k
+            for (int e = tid; e < nA; e += NTHREADS) {
+                int kk = e % BKV;
+                int i = (e / BKV) % BMT;
+                int tap = e / (BKV * BMT);
+                int m = m0 + i, k = k0 + kk;
+                float wv = 0.f;
+                if (m < a.M && k < a.K) wv = a.w[m * a.ws_m + k * a.ws_k + tap * a.ws_t + a.w_off];
+                As[(tap * BMT + i) * BKVP + kk] = wv;
+            }
+        } else {                                       // transposed view: contiguous along m
+            for (int e = tid; e < nA; e += NTHREADS) {
+                int i = e % BMT;
+                int kk = (e / BMT) % BKV;
+                int tap = e / (BKV * BMT);
+                int m = m0 + i, k = k0 + kk;
+                float wv = 0.f;
+                if (m < a.M && k < a.K) wv = a.w[m * a.ws_m + k * a.ws_k + tap * a.ws_t + a.w_off];
+                As[(tap * BMT + i) * BKVP + kk] = wv;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            if (p_kk[i] >= 0) {
+                int k = k0 + p_kk[i];
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p_ok[i] && k < a.K) {
+                    float c1 = cf[k], c2 = cf[a.K + k], c0 = cf[2 * a.K + k];
+                    o.x = fmaf(c1, r1[i].x, fmaf(c2, r2[i].x, c0)); o.y = fmaf(c1, r1[i].y, fmaf(c2, r2[i].y, c0));
+                    o.z = fmaf(c1, r1[i].z, fmaf(c2, r2[i].z, c0)); o.w = fmaf(c1, r1[i].w, fmaf(c2, r2[i].w, c0));
+                    if (a.src.act == 1) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+                }
+                *reinterpret_cast<float4*>(Bs + p_lds[i]) = o;
+            }
+        }
+        __syncthreads();
+        if (k0 + BKV < a.K) prefetch(k0 + BKV);        // in flight under the MFMAs below
+        for (int tap = 0; tap < a.KT; ++tap) {         // branch-free MFMA block: MT x CWT tiles per k-step
+            const float* at = arow + tap * BMT * BKVP;
+            const float* bt_ = Bs + kq * a.pitchB + tap * a.dil * V;
+#pragma unroll
+            for (int k4 = 0; k4 < BKV / 4; ++k4) {
+                float av[MT], bv[CWT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) av[mt] = at[mt * 16 * BKVP + k4 * 4];
+#pragma unroll
+                for (int c = 0; c < CWT; ++c) bv[c] = bt_[k4 * 4 * a.pitchB + boff[c]];
+#pragma unroll
+                for (int c = 0; c < CWT; ++c)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt][c] = mfma16(av[mt], bv[c], acc[mt][c]);
+            }
+        }
+    }
+
+    // ---- epilogue (same arithmetic as conv_epilogue, compile-time tile counts)
+    float s1[MT][4], s2[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { s1[mt][r] = 0.f; s2[mt][r] = 0.f; }
-
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        if (mt >= mt_act) continue;
+    for (int c = 0; c < CWT; ++c) {
+        int col = (cw0 + c) * 16 + j;
+        if (col >= ncols) continue;
+        int t = (t0 + tl[c]) * a.ostride;
 #pragma unroll
-        for (int c = 0; c < MAXCW; ++c) {
-            if (c >= c_act) continue;
-            int col = (cw0 + c) * 16 + j;
-            if (col >= ncols) continue;
-            int t = (t0 + tl[c]) * a.ostride;
+        for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 int m = m0 + mt * 16 + kq * 4 + r;
@@ -180,7 +395,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel(const ConvArgs a) {
     }
     if (a.stats_part) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float u1 = wave_sum16(s1[mt][r]);
@@ -195,7 +410,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel(const ConvArgs a) {
         if (tid < 2 * BM) {
             int st = tid >> 6, row = tid & 63;
             int m = m0 + row;
-            if (m < a.M) {
+            if (row < BMT && m < a.M) {
                 float tot = Ss[(st * 4 + 0) * BM + row] + Ss[(st * 4 + 1) * BM + row] +
                             Ss[(st * 4 + 2) * BM + row] + Ss[(st * 4 + 3) * BM + row];
                 int part = n * gridDim.x + blockIdx.x;
@@ -205,11 +420,12 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel(const ConvArgs a) {
     }
 }
 
-struct ConvPlan { int BT, CW, TIN, lstride, sB, LB, pitchB, ntt; size_t lds; };
+struct ConvPlan { int BT, CW, TIN, lstride, sB, LB, pitchB, ntt, bk, mt, cwt; bool vec; size_t lds; };
 
 static int plan_conv(const tamgcn_conv_desc* d, ConvPlan* p) {
     int V = d->V;
     if (V < 1 || V > MAXCOLS) return -1;
+    const bool vec_ok = (V % 4 == 0) && d->K <= 1024;
     int BT = MAXCOLS / V; if (BT < 1) BT = 1;
     if (BT > d->T_out) BT = d->T_out;
     for (;;) {
@@ -222,7 +438,19 @@ static int plan_conv(const tamgcn_conv_desc* d, ConvPlan* p) {
         pitch += ((16 - (pitch & 31)) + 32) & 31;          // pitch == 16 (mod 32)
         p->pitchB = pitch;
         p->CW = ceil_div(ceil_div(BT * V, 16), 4);
-        p->lds = sizeof(float) * ((size_t)d->KT * BM * BKP + (size_t)BK * pitch + 2 * 4 * BM);
+        p->vec = false; p->bk = BK;
+        if (vec_ok) {
+            // BK = 32 when the activation chunk fits 10 float4 per thread, else 16 (8 per thread)
+            int lb4 = p->LB / 4;
+            int bk = (d->KT == 1 && 32 * lb4 <= 10 * NTHREADS) ? 32 : 16;
+            if (bk * lb4 <= ((bk == 32) ? 10 : 8) * NTHREADS) { p->vec = true; p->bk = bk; }
+        }
+        // output-channel tile: 16*mt rows, mt chosen so that M splits without a half-empty tile
+        p->mt = d->M <= 16 ? 1 : d->M <= 32 ? 2 : (d->M % 64 == 0 ? 4 : (d->M % 48 == 0 ? 3 : 4));
+        p->cwt = p->CW <= 3 ? 3 : 5;
+        p->lds = p->vec ? sizeof(float) * ((((size_t)d->KT * p->mt * 16 * (p->bk + 2) + 3) & ~(size_t)3) + (size_t)p->bk * pitch +
+                                           2 * 4 * BM + 3 * (size_t)d->K)
+                        : sizeof(float) * ((size_t)d->KT * BM * (BK + 1) + (size_t)BK * pitch + 2 * 4 * BM);
         if (p->lds <= 64 * 1024 || BT == 1) break;
         BT = (BT + 1) / 2;
     }
@@ -256,7 +484,7 @@ extern "C" int tamgcn_conv(const tamgcn_conv_desc* d, void* stream) {
     a.w = d->w; a.bias = d->bias; a.M = d->M; a.KT = d->KT; a.dil = d->dil; a.stride = d->stride; a.pad = d->pad;
     if (d->wmode == 0) { a.ws_m = (long long)d->K * d->KT; a.ws_k = d->KT; a.ws_t = 1; a.w_off = 0; }
     else { a.ws_m = d->KT; a.ws_k = (long long)d->M * d->KT; a.ws_t = -1; a.w_off = d->KT - 1; }
-    a.up = d->up;
+    a.up = d->up; a.wmode = d->wmode;
     a.y = d->y; a.yctot = d->yctot; a.ycoff = d->ycoff; a.T_out = d->T_out; a.T_y = d->T_y; a.ostride = d->ostride;
     a.add1 = d->add1; a.add2 = d->add2; a.bcast = d->bcast; a.bcast_scale = d->bcast_scale;
     a.has_mask = d->mask != nullptr; a.mask = d->mask ? make_src(*d->mask) : null_src();
@@ -266,15 +494,39 @@ extern "C" int tamgcn_conv(const tamgcn_conv_desc* d, void* stream) {
     a.nparts = d->N * p.ntt;
     a.BT = p.BT; a.CW = p.CW; a.TIN = p.TIN; a.lstride = p.lstride; a.sB = p.sB; a.LB = p.LB; a.pitchB = p.pitchB;
     dim3 grid(p.ntt, ceil_div(d->M, BM), d->N);
-    if (p.lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
-    hipLaunchKernelGGL(conv_kernel, grid, dim3(NTHREADS), p.lds, (hipStream_t)stream, a);
+    if (p.vec) {
+        dim3 gridv(p.ntt, ceil_div(d->M, 16 * p.mt), d->N);
+#define TG_CONV_CASE(BKV_, MT_, CW_)                                                                              \
+        if (p.bk == BKV_ && p.mt == MT_ && p.cwt == CW_) {                                                         \
+            if (p.lds > 64 * 1024)                                                                                 \
+                (void)hipFuncSetAttribute((const void*)conv_kernel_vec<BKV_, MT_, CW_>,                            \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);                 \
+            hipLaunchKernelGGL((conv_kernel_vec<BKV_, MT_, CW_>), gridv, dim3(NTHREADS), p.lds, (hipStream_t)stream, a); \
+        } else
+        TG_CONV_CASE(32, 4, 5) TG_CONV_CASE(32, 3, 5) TG_CONV_CASE(32, 2, 5) TG_CONV_CASE(32, 1, 5)
+        TG_CONV_CASE(32, 4, 3) TG_CONV_CASE(32, 3, 3) TG_CONV_CASE(32, 2, 3) TG_CONV_CASE(32, 1, 3)
+        TG_CONV_CASE(16, 4, 5) TG_CONV_CASE(16, 3, 5) TG_CONV_CASE(16, 2, 5) TG_CONV_CASE(16, 1, 5)
+        TG_CONV_CASE(16, 4, 3) TG_CONV_CASE(16, 3, 3) TG_CONV_CASE(16, 2, 3) TG_CONV_CASE(16, 1, 3)
+        { tamgcn_set_error("tamgcn_conv: no instantiation bk=%d mt=%d cw=%d", p.bk, p.mt, p.cwt); return -1; }
+#undef TG_CONV_CASE
+    } else {
+        if (p.lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
+        hipLaunchKernelGGL(conv_kernel, grid, dim3(NTHREADS), p.lds, (hipStream_t)stream, a);
+    }
     TG_LAUNCH_CHECK("tamgcn_conv");
     return 0;
 }
 
 // ===========================================================================
-// weight gradient
+// weight gradient:  dW[m][k][tap] = sum_{n,t,v} gy(n,m,t,v) * x(n,k,t*stride + tap*dil - pad, v)
+//
+// An "NT" GEMM whose contraction index p = (n,t,v) is the contiguous axis of BOTH operands.
+// A workgroup owns a (2*WMT*16) x (2*WKT*16) tile of dW for all taps (2x2 waves, one
+// sub-tile per wave, accumulators never leave registers), walks its share of the samples in
+// chunks of BT frames, stages both operand tiles in LDS with 16-byte global loads (rows are
+// contiguous along t*V+v), the BatchNorm(-backward)-apply prologue fused into the fill, and
+// feeds v_mfma_f32_16x16x4_f32 with column reads that are bank-conflict free for pitches
+// == 2 (mod 4).  Partial slabs per n-split are summed by reduce_sum (deterministic).
 // ===========================================================================
 namespace {
 
@@ -282,150 +534,209 @@ struct WgradArgs {
     SrcDev gy, src;
     int N, M, K, T_in, T_out, V, dil, stride, pad;
     float* part; int nsplit;
-    int BMW, BKW;     // tile of dW (multiples of 16, <= 64)
-    int BT, TIN;      // frames per staged tile
-    int PY, PX;       // LDS pitches (odd)
+    int BT, TIN;      // frames per staged chunk (gy side / x side)
+    int PY, PX;       // LDS pitches
     int n_per;        // samples per split
 };
 
-template <int KT, int MTW, int KTW>
+__device__ __forceinline__ float wg_apply(float x1, float x2, float c1, float c2, float c0, int act) {
+    float v = fmaf(c1, x1, fmaf(c2, x2, c0));
+    return act == 1 ? fmaxf(v, 0.f) : v;
+}
+
+// fill rows [r0, r0+rows) x [0, len) of an LDS tile from channel-rows of `s`; frames outside
+// [0, T) are zero.  f0 = first frame of the tile, V4 = V/4 (VEC) .
+template <bool VEC>
+__device__ __forceinline__ void wg_fill(float* tile, int pitch, const float* cf, int rows, int nvalid, int ch0,
+                                        const SrcDev& s, long long nbase, long long cs, int T, int V, int f0, int frames) {
+    const int tid = threadIdx.x;
+    const int len = frames * V;
+    if constexpr (VEC) {
+        const int l4 = len >> 2;
+        for (int e = tid; e < rows * l4; e += NTHREADS) {
+            int r = e / l4, c4 = e - r * l4;
+            int col = c4 << 2;
+            int fr = f0 + col / V;
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < nvalid && fr >= 0 && fr < T) {
+                long long g = nbase + (long long)(ch0 + r) * cs + (long long)f0 * V + col;
+                float4 a = *reinterpret_cast<const float4*>(s.x1 + g);
+                float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (s.x2) b = *reinterpret_cast<const float4*>(s.x2 + g);
+                float c1 = cf[r], c2 = cf[rows + r], c0 = cf[2 * rows + r];
+                o.x = wg_apply(a.x, b.x, c1, c2, c0, s.act); o.y = wg_apply(a.y, b.y, c1, c2, c0, s.act);
+                o.z = wg_apply(a.z, b.z, c1, c2, c0, s.act); o.w = wg_apply(a.w, b.w, c1, c2, c0, s.act);
+            }
+            float2* d = reinterpret_cast<float2*>(tile + r * pitch + col);
+            d[0] = make_float2(o.x, o.y);
+            d[1] = make_float2(o.z, o.w);
+        }
+    } else {
+        for (int e = tid; e < rows * len; e += NTHREADS) {
+            int r = e / len, col = e - r * len;
+            int fr = f0 + col / V;
+            float o = 0.f;
+            if (r < nvalid && fr >= 0 && fr < T) {
+                long long g = nbase + (long long)(ch0 + r) * cs + (long long)f0 * V + col;
+                o = wg_apply(s.x1[g], s.x2 ? s.x2[g] : 0.f, cf[r], cf[rows + r], cf[2 * rows + r], s.act);
+            }
+            tile[r * pitch + col] = o;
+        }
+    }
+}
+
+template <int KT, int WMT, int WKT, bool VEC>
 __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int BMW = MTW * 16, BKW = KTW * 16;
+    constexpr int BMW = 2 * WMT * 16, BKW = 2 * WKT * 16;
     float* Ys = smem;                         // [BMW][PY]
     float* Xs = Ys + BMW * a.PY;              // [BKW][PX]
+    float* cfY = Xs + BKW * a.PX;             // [3][BMW]
+    float* cfX = cfY + 3 * BMW;               // [3][BKW]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kq = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;
     const int k0 = blockIdx.x * BKW, m0 = blockIdx.y * BMW, split = blockIdx.z;
     const int V = a.V, V4 = (V + 3) >> 2;
     const int n_begin = split * a.n_per, n_end = min(a.N, n_begin + a.n_per);
+    const int mvalid = min(BMW, a.M - m0), kvalid = min(BKW, a.K - k0);
 
-    f32x4 acc[KT][MTW][KTW];
+    for (int e = tid; e < BMW; e += NTHREADS) {
+        int ch = a.gy.coff + m0 + e;
+        bool ok = e < mvalid && a.gy.coef;
+        cfY[e] = ok ? a.gy.coef[ch] : 1.f;
+        cfY[BMW + e] = (ok && a.gy.x2) ? a.gy.coef[a.gy.ctot + ch] : 0.f;
+        cfY[2 * BMW + e] = ok ? a.gy.coef[2 * a.gy.ctot + ch] : 0.f;
+    }
+    for (int e = tid; e < BKW; e += NTHREADS) {
+        int ch = a.src.coff + k0 + e;
+        bool ok = e < kvalid && a.src.coef;
+        cfX[e] = ok ? a.src.coef[ch] : 1.f;
+        cfX[BKW + e] = (ok && a.src.x2) ? a.src.coef[a.src.ctot + ch] : 0.f;
+        cfX[2 * BKW + e] = ok ? a.src.coef[2 * a.src.ctot + ch] : 0.f;
+    }
+
+    f32x4 acc[KT][WMT][WKT];
 #pragma unroll
     for (int t = 0; t < KT; ++t)
 #pragma unroll
-        for (int x = 0; x < MTW; ++x)
+        for (int x = 0; x < WMT; ++x)
 #pragma unroll
-            for (int y = 0; y < KTW; ++y) acc[t][x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int y = 0; y < WKT; ++y) acc[t][x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const long long gy_cs = (long long)a.T_out * V, x_cs = (long long)a.T_in * V;
+    const float* yrow = Ys + (wr * WMT * 16 + j) * a.PY;
+    const float* xrow = Xs + (wc * WKT * 16 + j) * a.PX;
     for (int n = n_begin; n < n_end; ++n) {
         for (int t0 = 0; t0 < a.T_out; t0 += a.BT) {
             const int bt = min(a.BT, a.T_out - t0);
-            const int ncols = bt * V;
-            const int tin0 = t0 * a.stride - a.pad;
             const int tin = (bt - 1) * a.stride + (KT - 1) * a.dil + 1;
-            const int LX = tin * V;
             __syncthreads();
-            for (int pos = tid; pos < ncols; pos += NTHREADS) {
-                long long goff = (long long)n * a.gy.ctot * gy_cs + (long long)t0 * V + pos;
-                for (int i = 0; i < BMW; ++i) {
-                    int m = m0 + i;
-                    float v = 0.f;
-                    if (m < a.M) { int ch = a.gy.coff + m; v = src_value(a.gy, goff + ch * gy_cs, ch); }
-                    Ys[i * a.PY + pos] = v;
-                }
-            }
-            for (int pos = tid; pos < LX; pos += NTHREADS) {
-                int slot = pos / V;
-                int v = pos - slot * V;
-                int th = tin0 + slot;
-                bool ok = th >= 0 && th < a.T_in;
-                long long goff = (long long)n * a.src.ctot * x_cs + (long long)th * V + v;
-                for (int i = 0; i < BKW; ++i) {
-                    int k = k0 + i;
-                    float xv = 0.f;
-                    if (ok && k < a.K) { int ch = a.src.coff + k; xv = src_value(a.src, goff + ch * x_cs, ch); }
-                    Xs[i * a.PX + pos] = xv;
-                }
-            }
+            wg_fill<VEC>(Ys, a.PY, cfY, BMW, mvalid, a.gy.coff + m0, a.gy, (long long)n * a.gy.ctot * gy_cs, gy_cs,
+                         a.T_out, V, t0, bt);
+            wg_fill<VEC>(Xs, a.PX, cfX, BKW, kvalid, a.src.coff + k0, a.src, (long long)n * a.src.ctot * x_cs, x_cs,
+                         a.T_in, V, t0 * a.stride - a.pad, tin);
             __syncthreads();
-            const int nsteps = bt * V4;
-            for (int st = wave; st < nsteps; st += 4) {
-                int tloc = st / V4;
-                int v = (st - tloc * V4) * 4 + kq;
-                bool vok = v < V;
-                int vc = vok ? v : 0;
-                float av[MTW];
+            for (int tl = 0; tl < bt; ++tl) {
+#pragma unroll 5
+                for (int v4 = 0; v4 < V4; ++v4) {
+                    int v = v4 * 4 + kq;
+                    bool vok = VEC || v < V;
+                    int vc = vok ? v : 0;
+                    float av[WMT];
 #pragma unroll
-                for (int x = 0; x < MTW; ++x) {
-                    float t = Ys[(x * 16 + j) * a.PY + tloc * V + vc];
-                    av[x] = vok ? t : 0.f;
-                }
+                    for (int x = 0; x < WMT; ++x) {
+                        float t = yrow[x * 16 * a.PY + tl * V + vc];
+                        av[x] = vok ? t : 0.f;
+                    }
 #pragma unroll
-                for (int tap = 0; tap < KT; ++tap) {
-                    int xo = (tloc * a.stride + tap * a.dil) * V + vc;
+                    for (int tap = 0; tap < KT; ++tap) {
+                        const int xo = (tl * a.stride + tap * a.dil) * V + vc;
 #pragma unroll
-                    for (int y = 0; y < KTW; ++y) {
-                        float bv = Xs[(y * 16 + j) * a.PX + xo];
+                        for (int y = 0; y < WKT; ++y) {
+                            float bv = xrow[y * 16 * a.PX + xo];
 #pragma unroll
-                        for (int x = 0; x < MTW; ++x) acc[tap][x][y] = mfma16(av[x], bv, acc[tap][x][y]);
+                            for (int x = 0; x < WMT; ++x) acc[tap][x][y] = mfma16(av[x], bv, acc[tap][x][y]);
+                        }
                     }
                 }
             }
         }
     }
-    // cross-wave reduction through LDS, then one plain store per element
-    __syncthreads();
-    float* Rs = smem;                          // [KT][BMW][BKW]
-    for (int e = tid; e < KT * BMW * BKW; e += NTHREADS) Rs[e] = 0.f;
-    __syncthreads();
+    float* out = a.part + (long long)split * a.M * a.K * KT;
 #pragma unroll
     for (int tap = 0; tap < KT; ++tap)
 #pragma unroll
-        for (int x = 0; x < MTW; ++x)
+        for (int x = 0; x < WMT; ++x)
 #pragma unroll
-            for (int y = 0; y < KTW; ++y)
+            for (int y = 0; y < WKT; ++y)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    atomicAdd(&Rs[(tap * BMW + x * 16 + kq * 4 + r) * BKW + y * 16 + j], acc[tap][x][y][r]);
-    __syncthreads();
-    float* out = a.part + (long long)split * a.M * a.K * KT;
-    for (int e = tid; e < KT * BMW * BKW; e += NTHREADS) {
-        int kk = e % BKW;
-        int i = (e / BKW) % BMW;
-        int tap = e / (BKW * BMW);
-        int m = m0 + i, k = k0 + kk;
-        if (m < a.M && k < a.K) out[((long long)m * a.K + k) * KT + tap] = Rs[e];
-    }
+                for (int r = 0; r < 4; ++r) {
+                    int m = m0 + (wr * WMT + x) * 16 + kq * 4 + r;
+                    int k = k0 + (wc * WKT + y) * 16 + j;
+                    if (m < a.M && k < a.K) out[((long long)m * a.K + k) * KT + tap] = acc[tap][x][y][r];
+                }
 }
 
-template <int KT, int MTW, int KTW>
+static inline int even_pitch(int n) {      // smallest p >= n with p == 2 (mod 4): conflict-free column reads, 8-byte rows
+    int p = (n + 3) & ~3;
+    return p + 2;
+}
+
+template <int KT, int WMT, int WKT>
 static int launch_wgrad(WgradArgs& a, hipStream_t s) {
-    constexpr int BMW = MTW * 16, BKW = KTW * 16;
-    a.BMW = BMW; a.BKW = BKW;
-    int V = a.V;
-    int BT = 160 / V; if (BT < 1) BT = 1; if (BT > a.T_out) BT = a.T_out;
+    constexpr int BMW = 2 * WMT * 16, BKW = 2 * WKT * 16;
+    const int V = a.V;
+    const bool vec = (V % 4) == 0;
+    int BT = 8;
+    if (BT > a.T_out) BT = a.T_out;
     size_t lds;
     for (;;) {
         a.BT = BT;
         a.TIN = (BT - 1) * a.stride + (KT - 1) * a.dil + 1;
-        a.PY = (BT * V) | 1;
-        a.PX = (a.TIN * V) | 1;
-        lds = sizeof(float) * ((size_t)BMW * a.PY + (size_t)BKW * a.PX);
-        size_t red = sizeof(float) * (size_t)KT * BMW * BKW;
-        if (lds < red) lds = red;
-        if (lds <= 64 * 1024 || BT == 1) break;
-        BT = (BT + 1) / 2;
+        a.PY = even_pitch(BT * V);
+        a.PX = even_pitch(a.TIN * V);
+        lds = sizeof(float) * ((size_t)BMW * a.PY + (size_t)BKW * a.PX + 3 * (BMW + BKW));
+        if (lds <= 48 * 1024 || BT == 1) break;
+        BT = BT / 2;
     }
     if (lds > 160 * 1024) { tamgcn_set_error("tamgcn_wgrad: tile does not fit LDS (V=%d)", V); return -1; }
-    int mt = ceil_div(a.M, BMW), kt = ceil_div(a.K, BKW);
     a.n_per = ceil_div(a.N, a.nsplit);
-    dim3 grid(kt, mt, a.nsplit);
-    if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)wgrad_kernel<KT, MTW, KTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((wgrad_kernel<KT, MTW, KTW>), grid, dim3(NTHREADS), lds, s, a);
+    dim3 grid(ceil_div(a.K, BKW), ceil_div(a.M, BMW), a.nsplit);
+    if (vec) {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)wgrad_kernel<KT, WMT, WKT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((wgrad_kernel<KT, WMT, WKT, true>), grid, dim3(NTHREADS), lds, s, a);
+    } else {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)wgrad_kernel<KT, WMT, WKT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((wgrad_kernel<KT, WMT, WKT, false>), grid, dim3(NTHREADS), lds, s, a);
+    }
     return 0;
 }
 
-__global__ void reduce_sum_kernel(const float* part, int nsplit, long long stride_s, long long count,
-                                  float scale, int accumulate, float* out) {
-    long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= count) return;
+// tile shape chosen from (M, K, KT); the host wrapper uses the same rule to size nsplit
+static void wgrad_tile(int M, int K, int KT, int* wmt, int* wkt) {
+    if (KT == 1) { *wmt = M <= 64 ? 2 : 4; *wkt = K <= 64 ? 2 : 4; }
+    else if (KT == 9) { *wmt = 1; *wkt = 1; }
+    else { *wmt = M <= 32 ? 1 : 2; *wkt = K <= 32 ? 1 : 2; if (*wmt != *wkt) { *wmt = 2; *wkt = 2; } }
+}
+
+// out[e] = sum_s part[s][e]: 64 consecutive e per block (coalesced), the split axis spread over
+// the 4 waves of the block, fp64 accumulation, fixed order => deterministic.
+__global__ __launch_bounds__(256) void reduce_sum_kernel(const float* part, int nsplit, long long stride_s, long long count,
+                                                         float scale, int accumulate, float* out) {
+    __shared__ double red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long e = (long long)blockIdx.x * 64 + lane;
     double s = 0.0;
-    for (int k = 0; k < nsplit; ++k) s += (double)part[k * stride_s + e];
-    float r = (float)(s * (double)scale);
-    out[e] = accumulate ? out[e] + r : r;
+    if (e < count)
+        for (int k = w; k < nsplit; k += 4) s += (double)part[k * stride_s + e];
+    red[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && e < count) {
+        double t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        float r = (float)(t * (double)scale);
+        out[e] = accumulate ? out[e] + r : r;
+    }
 }
 
 }  // namespace
@@ -441,13 +752,18 @@ extern "C" int tamgcn_wgrad(const tamgcn_wgrad_desc* d, void* stream) {
     a.N = d->N; a.M = d->M; a.K = d->K; a.T_in = d->T_in; a.T_out = d->T_out; a.V = d->V;
     a.dil = d->dil; a.stride = d->stride; a.pad = d->pad; a.part = d->part; a.nsplit = d->nsplit;
     hipStream_t s = (hipStream_t)stream;
-    int rc;
-    bool small = d->M <= 32 && d->K <= 32;
+    int rc, wmt, wkt;
+    wgrad_tile(d->M, d->K, d->KT, &wmt, &wkt);
     switch (d->KT) {
-        case 1: rc = small ? launch_wgrad<1, 2, 2>(a, s) : launch_wgrad<1, 4, 4>(a, s); break;
-        case 3: rc = launch_wgrad<3, 2, 2>(a, s); break;
-        case 5: rc = launch_wgrad<5, 2, 2>(a, s); break;
-        case 9: rc = launch_wgrad<9, 2, 2>(a, s); break;
+        case 1:
+            if (wmt == 2 && wkt == 2) rc = launch_wgrad<1, 2, 2>(a, s);
+            else if (wmt == 4 && wkt == 2) rc = launch_wgrad<1, 4, 2>(a, s);
+            else if (wmt == 2 && wkt == 4) rc = launch_wgrad<1, 2, 4>(a, s);
+            else rc = launch_wgrad<1, 4, 4>(a, s);
+            break;
+        case 3: rc = wmt == 1 ? launch_wgrad<3, 1, 1>(a, s) : launch_wgrad<3, 2, 2>(a, s); break;
+        case 5: rc = wmt == 1 ? launch_wgrad<5, 1, 1>(a, s) : launch_wgrad<5, 2, 2>(a, s); break;
+        case 9: rc = launch_wgrad<9, 1, 1>(a, s); break;
         default: tamgcn_set_error("tamgcn_wgrad: kernel size %d not instantiated (1,3,5,9)", d->KT); return -1;
     }
     if (rc) return rc;
@@ -458,7 +774,7 @@ extern "C" int tamgcn_wgrad(const tamgcn_wgrad_desc* d, void* stream) {
 extern "C" int tamgcn_reduce_sum(const float* part, int nsplit, long long stride_s, long long count,
                                  float scale, int accumulate, float* out, void* stream) {
     TG_CHECK(part && out && nsplit > 0 && count > 0, "tamgcn_reduce_sum: bad args");
-    long long blocks = (count + 255) / 256;
+    long long blocks = (count + 63) / 64;
     hipLaunchKernelGGL(reduce_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        part, nsplit, stride_s, count, scale, accumulate, out);
     TG_LAUNCH_CHECK("tamgcn_reduce_sum");

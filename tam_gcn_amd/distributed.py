@@ -11,6 +11,13 @@ import torch.distributed as dist
 
 
 class FlatGradBucket:
+    """All gradients in ONE flat fp32 buffer => one all-reduce, no per-tensor collectives.
+
+    Autograd hands each parameter a freshly produced gradient tensor (``p.grad`` is None before
+    backward, so AccumulateGrad steals it: no 600 tiny in-place-add kernels per step); ``pack()``
+    gathers them into the bucket with one multi-tensor copy and re-points ``p.grad`` at the
+    bucket's views, which is what the optimiser then reads."""
+
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
@@ -18,13 +25,28 @@ class FlatGradBucket:
         dev, dt = self.params[0].device, self.params[0].dtype
         n = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(n, device=dev, dtype=dt)
+        self.views = []
         off = 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)     # autograd accumulates in place
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
 
     def zero(self):
-        self.flat.zero_()
+        for p in self.params:
+            p.grad = None
+
+    def pack(self):
+        grads = [p.grad for p in self.params]
+        if any(g is None for g in grads):                  # parameter unused this step
+            self.flat.zero_()
+            pairs = [(v, g) for v, g in zip(self.views, grads) if g is not None]
+            if pairs:
+                torch._foreach_copy_([v for v, _ in pairs], [g for _, g in pairs])
+        else:
+            torch._foreach_copy_(self.views, grads)
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+        return self.flat
 
     def all_reduce_mean(self, group=None):
         """Sum over ranks / world size: the gradient of the mean loss over the global batch

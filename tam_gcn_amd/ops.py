@@ -95,9 +95,15 @@ def wgrad(gy, src, M, K, KT=1, dil=1, stride=1, pad=0):
     """Returns dW (M, K, KT, 1)."""
     N, _, T_out, V = gy.x1.shape
     T_in = src.x1.shape[2]
-    tiles = ((M + 63) // 64) * ((K + 63) // 64) if KT == 1 and not (M <= 32 and K <= 32) \
-        else ((M + 31) // 32) * ((K + 31) // 32)
-    nsplit = max(1, min(N, 768 // max(1, tiles)))
+    # same tile rule as wgrad_tile() in csrc/conv.hip: aim at ~4 resident workgroups per CU
+    if KT == 1:
+        bm, bk = (64 if M <= 64 else 128), (64 if K <= 64 else 128)
+    elif KT == 9:
+        bm = bk = 32
+    else:
+        bm = bk = 32 if (M <= 32 and K <= 32) else 64
+    tiles = ((M + bm - 1) // bm) * ((K + bk - 1) // bk)
+    nsplit = max(1, min(N, (1024 + tiles - 1) // tiles))
     part = empty(nsplit, M, K, KT, like=gy.x1)
     d = WgradDesc()
     d.gy, d.src = gy.c(), src.c()

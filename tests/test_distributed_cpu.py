@@ -33,6 +33,7 @@ def _worker(rank, world, port, out):
     for _ in range(2):
         bucket.zero()
         torch.nn.functional.cross_entropy(net(X[lo:hi]), Y[lo:hi]).backward()
+        bucket.pack()
         bucket.all_reduce_mean()
         opt.step()
     out[rank] = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
