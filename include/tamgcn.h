@@ -115,8 +115,9 @@ typedef struct tamgcn_wgrad_desc {
 } tamgcn_wgrad_desc;
 int tamgcn_wgrad(const tamgcn_wgrad_desc* d, void* stream);
 
-/* out[e] = (accumulate ? out[e] : 0) + scale * sum_{s<nsplit} part[s*stride_s + e] */
-int tamgcn_reduce_sum(const float* part, int nsplit, long long stride_s, long long count,
+/* out[e] = (accumulate ? out[e] : 0) + scale * sum_{s<nsplit} part[s*stride_s + e]
+ * (fp64 accumulation, fixed order).  `part` is scratch: for nsplit > 128 it is reduced in place first. */
+int tamgcn_reduce_sum(float* part, int nsplit, long long stride_s, long long count,
                       float scale, int accumulate, float* out, void* stream);
 
 /* ------------------------------------------------------------------------

@@ -54,7 +54,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[4]
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { s1[mt][r] = 0.f; s2[mt][r] = 0.f; }
-
+    // pass 1: all loads (bias, broadcast, residual adds, mask, aux); results stay in acc
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         if (mt >= mt_act) continue;
@@ -79,13 +79,31 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[4]
                     long long midx = (((long long)n * a.mask.ctot + mch) * a.T_y + t) * V + vv[c];
                     if (!(src_value(a.mask, midx, mch) > 0.f)) val = 0.f;
                 }
-                a.y[idx] = val;
+                acc[mt][c][r] = val;
                 if (a.stats_part) {
                     float x2 = val;
                     if (a.aux) x2 = a.aux[(((long long)n * a.auxctot + a.auxcoff + m) * a.T_y + t) * V + vv[c]] - a.aux_center[a.auxcoff + m];
                     s1[mt][r] += val;
                     s2[mt][r] = fmaf(val, x2, s2[mt][r]);
                 }
+            }
+        }
+    }
+    // pass 2: stores only (vmcnt counts stores in order: never interleave loads with them)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        if (mt >= mt_act) continue;
+#pragma unroll
+        for (int c = 0; c < MAXCW; ++c) {
+            if (c >= c_act) continue;
+            int col = (cw0 + c) * 16 + j;
+            if (col >= ncols) continue;
+            int t = (t0 + tl[c]) * a.ostride;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int m = m0 + mt * 16 + kq * 4 + r;
+                if (m >= a.M) continue;
+                a.y[(((long long)n * a.yctot + a.ycoff + m) * a.T_y + t) * V + vv[c]] = acc[mt][c][r];
             }
         }
     }
@@ -281,6 +299,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel_vec(const ConvArgs a) {
     }
     float4 r1[NPF], r2[NPF];
     const bool has2 = a.src.x2 != nullptr;
+    // weight tile of a 1x1 conv (BMT*BKV floats) is prefetched as well: NAF values per thread
+    constexpr int NAF = (BMT * BKV + NTHREADS - 1) / NTHREADS;
+    const bool apf = a.KT == 1;
+    float wr[NAF];
     auto prefetch = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
@@ -292,6 +314,16 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel_vec(const ConvArgs a) {
                 if (has2) r2[i] = *reinterpret_cast<const float4*>(a.src.x2 + g);
             }
         }
+        if (apf) {
+#pragma unroll
+            for (int i = 0; i < NAF; ++i) {
+                int e = tid + i * NTHREADS;
+                int ii, kk;
+                if (a.wmode == 0) { kk = e % BKV; ii = e / BKV; } else { ii = e % BMT; kk = e / BMT; }
+                int m = m0 + ii, k = k0 + kk;
+                wr[i] = (e < BMT * BKV && m < a.M && k < a.K) ? a.w[m * a.ws_m + k * a.ws_k + a.w_off] : 0.f;
+            }
+        }
     };
     prefetch(0);
     __syncthreads();                                   // cf table visible
@@ -300,7 +332,15 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel_vec(const ConvArgs a) {
     for (int k0 = 0; k0 < a.K; k0 += BKV) {
         __syncthreads();                               // previous chunk's MFMAs done with As/Bs
         const int nA = a.KT * BMT * BKV;
-        if (a.wmode == 0) {                            // weight rows contiguous along k
+        if (apf) {
+#pragma unroll
+            for (int i = 0; i < NAF; ++i) {
+                int e = tid + i * NTHREADS;
+                int ii, kk;
+                if (a.wmode == 0) { kk = e % BKV; ii = e / BKV; } else { ii = e % BMT; kk = e / BMT; }
+                if (e < BMT * BKV) As[ii * BKVP + kk] = wr[i];
+            }
+        } else if (a.wmode == 0) {                     // weight rows contiguous along k
             for (int e = tid; e < nA; e += NTHREADS) {
                 int kk = e % BKV;
                 int i = (e / BKV) % BMT;
@@ -355,66 +395,100 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel_vec(const ConvArgs a) {
         }
     }
 
-    // ---- epilogue (same arithmetic as conv_epilogue, compile-time tile counts)
-    float s1[MT][4], s2[MT][4];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { s1[mt][r] = 0.f; s2[mt][r] = 0.f; }
-#pragma unroll
-    for (int c = 0; c < CWT; ++c) {
-        int col = (cw0 + c) * 16 + j;
-        if (col >= ncols) continue;
-        int t = (t0 + tl[c]) * a.ostride;
+    // ---- epilogue.  The accumulators are staged through LDS (the operand tiles are dead) and
+    // a compact loop finishes one float4 per iteration: bias / broadcast / residual adds / mask /
+    // BatchNorm moments with 16-byte coalesced loads and stores.  (A fully unrolled register
+    // epilogue was 90 KB of code: it thrashed the instruction cache and scaled with MT*CW.)
+    __syncthreads();                                   // all MFMA reads of As/Bs are done
+    float* Tt = smem;                                  // [rows_per_pass][PT]
+    constexpr int PT = CWT * 64 + 4;
+    const int avail = ((a.KT * BMT * BKVP + 3) & ~3) + BKV * a.pitchB;
+    int RP = (avail / PT) & ~15;                       // rows per pass: 16, 32, 48 or 64 (host checks >= 16)
+    if (RP > BMT) RP = BMT;
+    if (RP == 48) RP = 32;
+    const int TPR = NTHREADS / RP;                     // threads per row: 16, 8 or 4
+    const int nc4 = ncols >> 2;
+    if (a.stats_part) {
+        for (int e = tid; e < 2 * 4 * BM; e += NTHREADS) Ss[e] = 0.f;
+    }
+    for (int r0 = 0; r0 < BMT; r0 += RP) {
+        __syncthreads();
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
+            const int rl = mt * 16 + kq * 4 - r0;      // local row of this lane's first accumulator row
+            if (rl >= 0 && rl < RP) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int m = m0 + mt * 16 + kq * 4 + r;
-                if (m >= a.M) continue;
-                float val = acc[mt][c][r];
-                if (a.bias) val += a.bias[m];
-                long long idx = (((long long)n * a.yctot + a.ycoff + m) * a.T_y + t) * V + vv[c];
-                if (a.bcast) val = fmaf(a.bcast[((long long)m * a.N + n) * V + vv[c]], a.bcast_scale, val);
-                if (a.add1) val += a.add1[idx];
-                if (a.add2) val += a.add2[idx];
-                if (a.has_mask) {
-                    int mch = a.mask.coff + m;
-                    long long midx = (((long long)n * a.mask.ctot + mch) * a.T_y + t) * V + vv[c];
-                    if (!(src_value(a.mask, midx, mch) > 0.f)) val = 0.f;
-                }
-                a.y[idx] = val;
-                if (a.stats_part) {
-                    float x2 = val;
-                    if (a.aux) x2 = a.aux[(((long long)n * a.auxctot + a.auxcoff + m) * a.T_y + t) * V + vv[c]] - a.aux_center[a.auxcoff + m];
-                    s1[mt][r] += val;
-                    s2[mt][r] = fmaf(val, x2, s2[mt][r]);
+                for (int c = 0; c < CWT; ++c) {
+                    const int col = (cw0 + c) * 16 + j;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Tt[(rl + r) * PT + col] = acc[mt][c][r];
                 }
             }
         }
+        __syncthreads();
+        const int row = tid / TPR, seg = tid - row * TPR;
+        const int m = m0 + r0 + row;
+        float p1 = 0.f, p2 = 0.f;
+        const bool rowok = r0 + row < BMT && m < a.M;   // RP may overshoot the tile (BMT = 48, RP = 32)
+        if (rowok) {
+            const float bia = a.bias ? a.bias[m] : 0.f;
+            const float ctr = a.aux ? a.aux_center[a.auxcoff + m] : 0.f;
+            const long long ybase = ((long long)n * a.yctot + a.ycoff + m) * a.T_y * V;
+            const long long mbase = a.has_mask ? ((long long)n * a.mask.ctot + a.mask.coff + m) * a.T_y * V : 0;
+            const long long abase = a.aux ? ((long long)n * a.auxctot + a.auxcoff + m) * a.T_y * V : 0;
+            float mc1 = 1.f, mc2 = 0.f, mc0 = 0.f;
+            if (a.has_mask && a.mask.coef) {
+                int mch = a.mask.coff + m;
+                mc1 = a.mask.coef[mch]; mc0 = a.mask.coef[2 * a.mask.ctot + mch];
+                if (a.mask.x2) mc2 = a.mask.coef[a.mask.ctot + mch];
+            }
+            for (int c4 = seg; c4 < nc4; c4 += TPR) {
+                const int col = c4 << 2;
+                const int fr = col / V, v = col - fr * V;
+                const long long off = (long long)(t0 + fr) * a.ostride * V + v;
+                float4 val = *reinterpret_cast<const float4*>(Tt + row * PT + col);
+                val.x += bia; val.y += bia; val.z += bia; val.w += bia;
+                if (a.bcast) {
+                    float4 b = *reinterpret_cast<const float4*>(a.bcast + ((long long)m * a.N + n) * V + v);
+                    val.x = fmaf(b.x, a.bcast_scale, val.x); val.y = fmaf(b.y, a.bcast_scale, val.y);
+                    val.z = fmaf(b.z, a.bcast_scale, val.z); val.w = fmaf(b.w, a.bcast_scale, val.w);
+                }
+                if (a.add1) { float4 t = *reinterpret_cast<const float4*>(a.add1 + ybase + off); val.x += t.x; val.y += t.y; val.z += t.z; val.w += t.w; }
+                if (a.add2) { float4 t = *reinterpret_cast<const float4*>(a.add2 + ybase + off); val.x += t.x; val.y += t.y; val.z += t.z; val.w += t.w; }
+                if (a.has_mask) {
+                    float4 q = *reinterpret_cast<const float4*>(a.mask.x1 + mbase + off);
+                    float4 q2 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (a.mask.x2) q2 = *reinterpret_cast<const float4*>(a.mask.x2 + mbase + off);
+                    if (!(fmaf(mc1, q.x, fmaf(mc2, q2.x, mc0)) > 0.f)) val.x = 0.f;
+                    if (!(fmaf(mc1, q.y, fmaf(mc2, q2.y, mc0)) > 0.f)) val.y = 0.f;
+                    if (!(fmaf(mc1, q.z, fmaf(mc2, q2.z, mc0)) > 0.f)) val.z = 0.f;
+                    if (!(fmaf(mc1, q.w, fmaf(mc2, q2.w, mc0)) > 0.f)) val.w = 0.f;
+                }
+                if (a.stats_part) {
+                    float4 x2 = val;
+                    if (a.aux) {
+                        x2 = *reinterpret_cast<const float4*>(a.aux + abase + off);
+                        x2.x -= ctr; x2.y -= ctr; x2.z -= ctr; x2.w -= ctr;
+                    }
+                    p1 += (val.x + val.y) + (val.z + val.w);
+                    p2 = fmaf(val.x, x2.x, fmaf(val.y, x2.y, fmaf(val.z, x2.z, fmaf(val.w, x2.w, p2))));
+                }
+                *reinterpret_cast<float4*>(a.y + ybase + off) = val;
+            }
+        }
+        if (a.stats_part) {
+            for (int o = 1; o < TPR; o <<= 1) { p1 += __shfl_xor(p1, o); p2 += __shfl_xor(p2, o); }
+            if (seg == 0 && rowok) { Ss[r0 + row] = p1; Ss[4 * BM + r0 + row] = p2; }
+        }
     }
     if (a.stats_part) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float u1 = wave_sum16(s1[mt][r]);
-                float u2 = wave_sum16(s2[mt][r]);
-                if (j == 0) {
-                    int row = mt * 16 + kq * 4 + r;
-                    Ss[(0 * 4 + wave) * BM + row] = u1;
-                    Ss[(1 * 4 + wave) * BM + row] = u2;
-                }
-            }
         __syncthreads();
-        if (tid < 2 * BM) {
-            int st = tid >> 6, row = tid & 63;
+        if (tid < 2 * BMT) {
+            int st = tid / BMT, row = tid - st * BMT;
             int m = m0 + row;
-            if (row < BMT && m < a.M) {
-                float tot = Ss[(st * 4 + 0) * BM + row] + Ss[(st * 4 + 1) * BM + row] +
-                            Ss[(st * 4 + 2) * BM + row] + Ss[(st * 4 + 3) * BM + row];
+            if (m < a.M) {
                 int part = n * gridDim.x + blockIdx.x;
-                a.stats_part[((long long)st * a.stats_ctot + a.stats_coff + m) * a.nparts + part] = tot;
+                a.stats_part[((long long)st * a.stats_ctot + a.stats_coff + m) * a.nparts + part] = Ss[st * 4 * BM + row];
             }
         }
     }
@@ -448,6 +522,10 @@ static int plan_conv(const tamgcn_conv_desc* d, ConvPlan* p) {
         // output-channel tile: 16*mt rows, mt chosen so that M splits without a half-empty tile
         p->mt = d->M <= 16 ? 1 : d->M <= 32 ? 2 : (d->M % 64 == 0 ? 4 : (d->M % 48 == 0 ? 3 : 4));
         p->cwt = p->CW <= 3 ? 3 : 5;
+        if (p->vec) {                                       // staged epilogue needs >= 16 rows of (cwt*64+4) floats
+            size_t avail = (((size_t)d->KT * p->mt * 16 * (p->bk + 2) + 3) & ~(size_t)3) + (size_t)p->bk * pitch;
+            if (avail < (size_t)16 * (p->cwt * 64 + 4)) p->vec = false;
+        }
         p->lds = p->vec ? sizeof(float) * ((((size_t)d->KT * p->mt * 16 * (p->bk + 2) + 3) & ~(size_t)3) + (size_t)p->bk * pitch +
                                            2 * 4 * BM + 3 * (size_t)d->K)
                         : sizeof(float) * ((size_t)d->KT * BM * (BK + 1) + (size_t)BK * pitch + 2 * 4 * BM);
@@ -476,6 +554,7 @@ extern "C" int tamgcn_conv(const tamgcn_conv_desc* d, void* stream) {
     TG_CHECK(d->src.coff + d->K <= d->src.ctot && d->ycoff + d->M <= d->yctot, "tamgcn_conv: channel slice out of range");
     TG_CHECK((d->T_out - 1) * d->ostride < d->T_y, "tamgcn_conv: T_out*ostride exceeds T_y");
     TG_CHECK(!(d->N > 65535), "tamgcn_conv: N too large for grid.z");
+    TG_CHECK((long long)d->N * d->yctot * d->T_y * d->V < (1LL << 32), "tamgcn_conv: output tensor exceeds 2^32 elements");
     ConvPlan p;
     TG_CHECK(plan_conv(d, &p) == 0, "tamgcn_conv: no tiling for V=%d KT=%d dil=%d stride=%d", d->V, d->KT, d->dil, d->stride);
     ConvArgs a;
@@ -585,10 +664,13 @@ __device__ __forceinline__ void wg_fill(float* tile, int pitch, const float* cf,
     }
 }
 
+constexpr int WG_NPF = 6;     // float4 prefetch slots per thread and operand (1x1 weight-gradient pipeline)
+
 template <int KT, int WMT, int WKT, bool VEC>
 __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int BMW = 2 * WMT * 16, BKW = 2 * WKT * 16;
+    constexpr bool PF = VEC && KT == 1;       // register-prefetch pipeline (host guarantees the slot bound)
     float* Ys = smem;                         // [BMW][PY]
     float* Xs = Ys + BMW * a.PY;              // [BKW][PX]
     float* cfY = Xs + BKW * a.PX;             // [3][BMW]
@@ -627,16 +709,95 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(const WgradArgs a) {
     const long long gy_cs = (long long)a.T_out * V, x_cs = (long long)a.T_in * V;
     const float* yrow = Ys + (wr * WMT * 16 + j) * a.PY;
     const float* xrow = Xs + (wc * WKT * 16 + j) * a.PX;
+
+    // ---- prefetch descriptors (PF only): slot i of this thread -> (row, 4-column group) of each tile
+    const int ly4 = (a.BT * V) >> 2, lx4 = (a.TIN * V) >> 2;
+    int yr[PF ? WG_NPF : 1], yc[PF ? WG_NPF : 1], xr_[PF ? WG_NPF : 1], xc[PF ? WG_NPF : 1];
+    float4 y1[PF ? WG_NPF : 1], y2[PF ? WG_NPF : 1], x1[PF ? WG_NPF : 1], x2[PF ? WG_NPF : 1];
+    if constexpr (PF) {
+#pragma unroll
+        for (int i = 0; i < WG_NPF; ++i) {
+            int e = tid + i * NTHREADS;
+            int r = e / ly4; yr[i] = r < BMW ? r : -1; yc[i] = (e - r * ly4) << 2;
+            r = e / lx4; xr_[i] = r < BKW ? r : -1; xc[i] = (e - r * lx4) << 2;
+        }
+    }
+    const bool gy2 = a.gy.x2 != nullptr, sx2 = a.src.x2 != nullptr;
+    auto prefetch = [&](int n, int t0) {
+        if constexpr (PF) {
+            const long long yb = (long long)n * a.gy.ctot * gy_cs + (long long)(a.gy.coff + m0) * gy_cs + (long long)t0 * V;
+            const int f0 = t0 * a.stride - a.pad;
+            const long long xb = (long long)n * a.src.ctot * x_cs + (long long)(a.src.coff + k0) * x_cs + (long long)f0 * V;
+#pragma unroll
+            for (int i = 0; i < WG_NPF; ++i) {
+                y1[i] = make_float4(0.f, 0.f, 0.f, 0.f); y2[i] = y1[i]; x1[i] = y1[i]; x2[i] = y1[i];
+                if (yr[i] >= 0 && yr[i] < mvalid && t0 + yc[i] / V < a.T_out) {
+                    long long g = yb + (long long)yr[i] * gy_cs + yc[i];
+                    y1[i] = *reinterpret_cast<const float4*>(a.gy.x1 + g);
+                    if (gy2) y2[i] = *reinterpret_cast<const float4*>(a.gy.x2 + g);
+                }
+                int fr = f0 + xc[i] / V;
+                if (xr_[i] >= 0 && xr_[i] < kvalid && fr >= 0 && fr < a.T_in) {
+                    long long g = xb + (long long)xr_[i] * x_cs + xc[i];
+                    x1[i] = *reinterpret_cast<const float4*>(a.src.x1 + g);
+                    if (sx2) x2[i] = *reinterpret_cast<const float4*>(a.src.x2 + g);
+                }
+            }
+        }
+    };
+    auto commit = [&](int n, int t0) {        // prologue + LDS store of the prefetched chunk (zeros where invalid)
+        if constexpr (PF) {
+            const int f0 = t0 * a.stride - a.pad;
+#pragma unroll
+            for (int i = 0; i < WG_NPF; ++i) {
+                if (yr[i] >= 0) {
+                    const int r = yr[i];
+                    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (r < mvalid && t0 + yc[i] / V < a.T_out) {
+                        float c1 = cfY[r], c2 = cfY[BMW + r], c0 = cfY[2 * BMW + r];
+                        o.x = wg_apply(y1[i].x, y2[i].x, c1, c2, c0, a.gy.act); o.y = wg_apply(y1[i].y, y2[i].y, c1, c2, c0, a.gy.act);
+                        o.z = wg_apply(y1[i].z, y2[i].z, c1, c2, c0, a.gy.act); o.w = wg_apply(y1[i].w, y2[i].w, c1, c2, c0, a.gy.act);
+                    }
+                    float2* d = reinterpret_cast<float2*>(Ys + r * a.PY + yc[i]);
+                    d[0] = make_float2(o.x, o.y); d[1] = make_float2(o.z, o.w);
+                }
+                if (xr_[i] >= 0) {
+                    const int r = xr_[i];
+                    const int fr = f0 + xc[i] / V;
+                    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (r < kvalid && fr >= 0 && fr < a.T_in) {
+                        float c1 = cfX[r], c2 = cfX[BKW + r], c0 = cfX[2 * BKW + r];
+                        o.x = wg_apply(x1[i].x, x2[i].x, c1, c2, c0, a.src.act); o.y = wg_apply(x1[i].y, x2[i].y, c1, c2, c0, a.src.act);
+                        o.z = wg_apply(x1[i].z, x2[i].z, c1, c2, c0, a.src.act); o.w = wg_apply(x1[i].w, x2[i].w, c1, c2, c0, a.src.act);
+                    }
+                    float2* d = reinterpret_cast<float2*>(Xs + r * a.PX + xc[i]);
+                    d[0] = make_float2(o.x, o.y); d[1] = make_float2(o.z, o.w);
+                }
+            }
+        }
+    };
+
+    __syncthreads();                          // coefficient tables visible
+    if (n_begin < n_end) prefetch(n_begin, 0);
     for (int n = n_begin; n < n_end; ++n) {
         for (int t0 = 0; t0 < a.T_out; t0 += a.BT) {
             const int bt = min(a.BT, a.T_out - t0);
             const int tin = (bt - 1) * a.stride + (KT - 1) * a.dil + 1;
             __syncthreads();
-            wg_fill<VEC>(Ys, a.PY, cfY, BMW, mvalid, a.gy.coff + m0, a.gy, (long long)n * a.gy.ctot * gy_cs, gy_cs,
-                         a.T_out, V, t0, bt);
-            wg_fill<VEC>(Xs, a.PX, cfX, BKW, kvalid, a.src.coff + k0, a.src, (long long)n * a.src.ctot * x_cs, x_cs,
-                         a.T_in, V, t0 * a.stride - a.pad, tin);
+            if constexpr (PF) {
+                commit(n, t0);
+            } else {
+                wg_fill<VEC>(Ys, a.PY, cfY, BMW, mvalid, a.gy.coff + m0, a.gy, (long long)n * a.gy.ctot * gy_cs, gy_cs,
+                             a.T_out, V, t0, bt);
+                wg_fill<VEC>(Xs, a.PX, cfX, BKW, kvalid, a.src.coff + k0, a.src, (long long)n * a.src.ctot * x_cs, x_cs,
+                             a.T_in, V, t0 * a.stride - a.pad, tin);
+            }
             __syncthreads();
+            if constexpr (PF) {               // next chunk's loads fly under this chunk's MFMAs
+                int nt0 = t0 + a.BT, nn = n;
+                if (nt0 >= a.T_out) { nt0 = 0; nn = n + 1; }
+                if (nn < n_end) prefetch(nn, nt0);
+            }
             for (int tl = 0; tl < bt; ++tl) {
 #pragma unroll 5
                 for (int v4 = 0; v4 < V4; ++v4) {
@@ -697,7 +858,12 @@ static int launch_wgrad(WgradArgs& a, hipStream_t s) {
         a.PY = even_pitch(BT * V);
         a.PX = even_pitch(a.TIN * V);
         lds = sizeof(float) * ((size_t)BMW * a.PY + (size_t)BKW * a.PX + 3 * (BMW + BKW));
-        if (lds <= 48 * 1024 || BT == 1) break;
+        bool slots_ok = !(vec && KT == 1) ||
+                        (BMW * (BT * V / 4) <= WG_NPF * NTHREADS && BKW * (a.TIN * V / 4) <= WG_NPF * NTHREADS);
+        if ((lds <= 48 * 1024 && slots_ok) || BT == 1) {
+            if (!slots_ok) { tamgcn_set_error("tamgcn_wgrad: prefetch slots exceeded (V=%d stride=%d)", V, a.stride); return -1; }
+            break;
+        }
         BT = BT / 2;
     }
     if (lds > 160 * 1024) { tamgcn_set_error("tamgcn_wgrad: tile does not fit LDS (V=%d)", V); return -1; }
@@ -771,10 +937,34 @@ extern "C" int tamgcn_wgrad(const tamgcn_wgrad_desc* d, void* stream) {
     return 0;
 }
 
-extern "C" int tamgcn_reduce_sum(const float* part, int nsplit, long long stride_s, long long count,
+// first stage for many splits: group g (64 splits) is summed in place into its first slab.  Only
+// the block owning (64 elements, group g) touches those slabs for those elements: race-free.
+__global__ __launch_bounds__(256) void reduce_group_kernel(float* part, int nsplit, long long stride_s, long long count) {
+    __shared__ double red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long e = (long long)blockIdx.x * 64 + lane;
+    const int s0 = blockIdx.y * 64, s1 = min(nsplit, s0 + 64);
+    double s = 0.0;
+    if (e < count)
+        for (int k = s0 + w; k < s1; k += 4) s += (double)part[k * stride_s + e];
+    red[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && e < count)
+        part[(long long)s0 * stride_s + e] = (float)((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
+}
+
+extern "C" int tamgcn_reduce_sum(float* part, int nsplit, long long stride_s, long long count,
                                  float scale, int accumulate, float* out, void* stream) {
     TG_CHECK(part && out && nsplit > 0 && count > 0, "tamgcn_reduce_sum: bad args");
     long long blocks = (count + 63) / 64;
+    if (nsplit > 128) {                                 // two stages (clobbers `part`, which is scratch)
+        int groups = (nsplit + 63) / 64;
+        TG_CHECK(groups <= 65535, "tamgcn_reduce_sum: too many splits");
+        hipLaunchKernelGGL(reduce_group_kernel, dim3((unsigned)blocks, groups), dim3(256), 0, (hipStream_t)stream,
+                           part, nsplit, stride_s, count);
+        nsplit = groups;
+        stride_s *= 64;
+    }
     hipLaunchKernelGGL(reduce_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        part, nsplit, stride_s, count, scale, accumulate, out);
     TG_LAUNCH_CHECK("tamgcn_reduce_sum");

@@ -491,11 +491,13 @@ __global__ __launch_bounds__(G::NT) void ctrgc_bwd_de_kernel(const CtrgcArgs a, 
     // (b) chain through conv4 / tanh, subset by subset, rel-channel chunk by chunk.
     // Row work (per channel) is done by 16 threads per channel: tid < 256.
     const float alpha = a.alpha[0];
-    const int RC = min(min(a.R, 8), a.regionB / VV);
+    const int RC = min(min(a.R, 16), a.regionB / VV) & ~3;
     const long long NV = (long long)a.N * V;
     float dalpha_acc = 0.f;
     const int c = tid >> 4, l16 = tid & 15;
     const bool rowthr = tid < 256;
+    const int lane = tid & 63, wave = tid >> 6, mj = lane & 15, mkq = lane >> 4;
+    constexpr int NTILE = (VV + 15) / 16;
     for (int s = 0; s < ST; ++s) {
         if (rowthr) {
             float db4raw = 0.f;
@@ -519,17 +521,17 @@ __global__ __launch_bounds__(G::NT) void ctrgc_bwd_de_kernel(const CtrgcArgs a, 
             __syncthreads();
             if (rowthr) {
                 // dW4raw[c][r] = sum_uv dE[c][uv] * D[r][uv]
-                float wacc[8];
+                float wacc[16];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) wacc[r] = 0.f;
+                for (int r = 0; r < 16; ++r) wacc[r] = 0.f;
                 for (int uv = l16; uv < VV; uv += 16) {
                     float de = DE[(s * CT + c) * VV + uv];
 #pragma unroll
-                    for (int r = 0; r < 8; ++r)
+                    for (int r = 0; r < 16; ++r)
                         if (r < rc) wacc[r] = fmaf(de, X3[r * VV + uv], wacc[r]);
                 }
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
+                for (int r = 0; r < 16; ++r) {
                     float wsum = wave_sum16(wacc[r]);
                     if (l16 == 0 && r < rc) {
                         long long wi = ((long long)s * a.Cout + c0 + c) * a.R + r0 + r;
@@ -539,15 +541,31 @@ __global__ __launch_bounds__(G::NT) void ctrgc_bwd_de_kernel(const CtrgcArgs a, 
                 }
             }
             __syncthreads();
-            // dS[r][uv] = alpha * (sum_c W4[c][r] dE[c][uv]) * (1 - D^2), in place over D
-            for (int e = tid; e < rc * VV; e += NT) {
-                int r = e / VV, uv = e - r * VV;
-                float acc = 0.f;
+            // dS[r][uv] = alpha * (sum_c W4[c][r] dE[c][uv]) * (1 - D^2), in place over D.
+            // MFMA: rows = rel-channels (<= 16), K = the 16 channels of the tile, cols = (u,v).
+            {
+                float aw[4];
 #pragma unroll
-                for (int cc = 0; cc < CT; ++cc)
-                    acc = fmaf(a.w4[((long long)s * a.Cout + c0 + cc) * a.R + r0 + r], DE[(s * CT + cc) * VV + uv], acc);
-                float d = X3[e];
-                X3[e] = alpha * acc * (1.f - d * d);
+                for (int k4 = 0; k4 < 4; ++k4)
+                    aw[k4] = (mj < rc) ? a.w4[((long long)s * a.Cout + c0 + k4 * 4 + mkq) * a.R + r0 + mj] : 0.f;
+                for (int ct = wave; ct < NTILE; ct += G::NW) {
+                    const int col = ct * 16 + mj;
+                    const int colc = col < VV ? col : 0;
+                    f32x4 dd = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; ++k4)
+                        dd = mfma16(aw[k4], DE[(s * CT + k4 * 4 + mkq) * VV + colc], dd);
+                    if (col < VV) {
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const int row = mkq * 4 + rr;
+                            if (row < rc) {
+                                float d = X3[row * VV + col];
+                                X3[row * VV + col] = alpha * dd[rr] * (1.f - d * d);
+                            }
+                        }
+                    }
+                }
             }
             __syncthreads();
             // dp[r][u] = sum_v dS ; dq[r][v] = -sum_u dS   (other channel tiles add to the same slots)
@@ -631,7 +649,7 @@ static void allow_lds(K kernel, size_t lds, bool* done) {
 #define CTRGC_LAUNCH(KERNEL, GEO, ST_, FLAG, ...)                                                              \
     do {                                                                                                       \
         static bool FLAG = false;                                                                              \
-        allow_lds(KERNEL<GEO, ST_>, 160 * 1024, &FLAG);                                                        \
+        allow_lds(KERNEL<GEO, ST_>, p.lds, &FLAG);   /* exact size: static LDS comes on top */                                                        \
         hipLaunchKernelGGL((KERNEL<GEO, ST_>), dim3(grid_blocks(a)), dim3(GEO::NT), p.lds, (hipStream_t)stream, __VA_ARGS__); \
     } while (0)
 
