@@ -64,7 +64,7 @@ class _Probe:
 
     def __getattr__(self, name):
         fn = getattr(self._lib, name)
-        if not name.startswith('tamgcn_') or name in ('tamgcn_last_error', 'tamgcn_version', 'tamgcn_conv_nparts',
+        if not name.startswith('tamgcn_') or name in ('tamgcn_last_error', 'tamgcn_last_kernel', 'tamgcn_version', 'tamgcn_conv_nparts',
                                                      'tamgcn_ew_nparts', 'tamgcn_ctrgc_lds_bytes'):
             return fn
 
@@ -76,7 +76,8 @@ class _Probe:
             e0.record()
             rc = fn(*args)
             e1.record()
-            self.records.append((name, e0, e1, _algorithmic(name, args)))
+            sym = self._lib.tamgcn_last_kernel().decode()
+            self.records.append((sym or name, e0, e1, _algorithmic(name, args)))
             return rc
         return wrapped
 
@@ -132,7 +133,8 @@ def instrumented_pass(step_fn, probe, steps):
 
 
 def roofline_of(agg):
-    """Roofline object for the ABI entry with the largest share of step time."""
+    """Roofline object for the kernel symbol with the largest share of step time (symbols as rocprofv3
+    prints them, minus the anonymous-namespace prefix and the argument list)."""
     timed = {k: v for k, v in agg.items() if v['bytes'] > 0}
     if not timed:
         return None, {}
@@ -144,7 +146,8 @@ def roofline_of(agg):
     traffic = None
     tpath = os.path.join(ROOT, 'profiles', 'traffic.json')        # filled from rocprofv3 --pmc passes
     if os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get(name)
+        t = json.load(open(tpath)).get(name)
+        traffic = t.get('hbm_bytes_per_launch') if isinstance(t, dict) else t
     common = dict(kernel=name, launches=a['calls'], avg_launch_us=1e3 * a['ms'] / a['calls'],
                   algorithmic_bytes_per_launch=a['bytes'] / a['calls'], algorithmic_flops_per_launch=a['flops'] / a['calls'],
                   hbm_frac=bw / HBM_PEAK, mfma_f32_frac=fl / F32_MFMA_PEAK, traffic=traffic)

@@ -51,6 +51,9 @@ typedef struct tamgcn_src {
  * --------------------------------------------------------------------- */
 int         tamgcn_version(void);
 const char* tamgcn_last_error(void);
+/* symbol (template arguments included) of the kernel the calling thread's last ABI call launched;
+ * lets a profiler attribute HIP-event timings to the rows of a rocprofv3 kernel trace */
+const char* tamgcn_last_kernel(void);
 /* bytes of LDS the CTRGC kernels need for (S subsets, V joints, R rel-channels);
  * <0 if the shape is unsupported.  Lets the host fail early and loudly. */
 int         tamgcn_ctrgc_lds_bytes(int S, int V, int R);

@@ -52,6 +52,7 @@ _SP = C.POINTER(Src)
 SIGNATURES = {
     'tamgcn_version': (_i, []),
     'tamgcn_last_error': (C.c_char_p, []),
+    'tamgcn_last_kernel': (C.c_char_p, []),
     'tamgcn_ctrgc_lds_bytes': (_i, [_i, _i, _i]),
     'tamgcn_conv_nparts': (_i, [C.POINTER(ConvDesc)]),
     'tamgcn_conv': (_i, [C.POINTER(ConvDesc), _p]),

@@ -97,6 +97,7 @@ extern "C" int tamgcn_bn_fwd_finalize(const float* part, int part_ctot, int part
     hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream,
                        part, part_ctot, part_coff, nparts, count, gamma, beta, running_mean, running_var,
                        num_batches_tracked, momentum, eps, training, coef, save, coef_ctot, coef_coff);
+    tamgcn_note_kernel("bn_fwd_finalize_kernel");
     TG_LAUNCH_CHECK("tamgcn_bn_fwd_finalize");
     return 0;
 }
@@ -111,6 +112,7 @@ extern "C" int tamgcn_bn_bwd_finalize(const float* part, int part_ctot, int part
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream,
                        part, part_ctot, part_coff, nparts, count, gamma, save, save_ctot, save_coff, training,
                        dgamma, dbeta, dbias_conv, coef, coef_ctot, coef_coff);
+    tamgcn_note_kernel("bn_bwd_finalize_kernel");
     TG_LAUNCH_CHECK("tamgcn_bn_bwd_finalize");
     return 0;
 }

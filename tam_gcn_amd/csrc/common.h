@@ -12,6 +12,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // host side: error reporting
 // ---------------------------------------------------------------------------
 void tamgcn_set_error(const char* fmt, ...);
+void tamgcn_note_kernel(const char* fmt, ...);   // symbol of the kernel the last ABI call launched (per thread)
 
 #define TG_CHECK(cond, ...)                         \
     do {                                            \

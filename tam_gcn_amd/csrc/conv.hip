@@ -581,6 +581,7 @@ extern "C" int tamgcn_conv(const tamgcn_conv_desc* d, void* stream) {
                 (void)hipFuncSetAttribute((const void*)conv_kernel_vec<BKV_, MT_, CW_>,                            \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);                 \
             hipLaunchKernelGGL((conv_kernel_vec<BKV_, MT_, CW_>), gridv, dim3(NTHREADS), p.lds, (hipStream_t)stream, a); \
+            tamgcn_note_kernel("conv_kernel_vec<%d, %d, %d>", BKV_, MT_, CW_);                                      \
         } else
         TG_CONV_CASE(32, 4, 5) TG_CONV_CASE(32, 3, 5) TG_CONV_CASE(32, 2, 5) TG_CONV_CASE(32, 1, 5)
         TG_CONV_CASE(32, 4, 3) TG_CONV_CASE(32, 3, 3) TG_CONV_CASE(32, 2, 3) TG_CONV_CASE(32, 1, 3)
@@ -591,6 +592,7 @@ extern "C" int tamgcn_conv(const tamgcn_conv_desc* d, void* stream) {
     } else {
         if (p.lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
         hipLaunchKernelGGL(conv_kernel, grid, dim3(NTHREADS), p.lds, (hipStream_t)stream, a);
+        tamgcn_note_kernel("conv_kernel");
     }
     TG_LAUNCH_CHECK("tamgcn_conv");
     return 0;
@@ -868,6 +870,7 @@ static int launch_wgrad(WgradArgs& a, hipStream_t s) {
     }
     if (lds > 160 * 1024) { tamgcn_set_error("tamgcn_wgrad: tile does not fit LDS (V=%d)", V); return -1; }
     a.n_per = ceil_div(a.N, a.nsplit);
+    tamgcn_note_kernel("wgrad_kernel<%d, %d, %d, %s>", KT, WMT, WKT, vec ? "true" : "false");
     dim3 grid(ceil_div(a.K, BKW), ceil_div(a.M, BMW), a.nsplit);
     if (vec) {
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)wgrad_kernel<KT, WMT, WKT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -967,6 +970,7 @@ extern "C" int tamgcn_reduce_sum(float* part, int nsplit, long long stride_s, lo
     }
     hipLaunchKernelGGL(reduce_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        part, nsplit, stride_s, count, scale, accumulate, out);
+    tamgcn_note_kernel("reduce_sum_kernel");
     TG_LAUNCH_CHECK("tamgcn_reduce_sum");
     return 0;
 }

@@ -651,6 +651,7 @@ static void allow_lds(K kernel, size_t lds, bool* done) {
         static bool FLAG = false;                                                                              \
         allow_lds(KERNEL<GEO, ST_>, p.lds, &FLAG);   /* exact size: static LDS comes on top */                                                        \
         hipLaunchKernelGGL((KERNEL<GEO, ST_>), dim3(grid_blocks(a)), dim3(GEO::NT), p.lds, (hipStream_t)stream, __VA_ARGS__); \
+        tamgcn_note_kernel(#KERNEL "<Geo<%d, %d, %d>, %d>", GEO::V, GEO::TB, GEO::NTQ, ST_);                           \
     } while (0)
 
 #define CTRGC_DISPATCH(KERNEL, ...)                                                                            \

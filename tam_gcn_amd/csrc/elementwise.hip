@@ -195,6 +195,7 @@ extern "C" int tamgcn_gcn_tail_fwd(const tamgcn_src* y, const tamgcn_src* o, con
     TG_CHECK(y && o && g && y->x1 && o->x1 && grid_ok(N, C), "tamgcn_gcn_tail_fwd: bad args");
     hipLaunchKernelGGL(gcn_tail_fwd_kernel, dim3(C, N), dim3(EW_THREADS), 0, (hipStream_t)stream,
                        make_src(*y), make_src(*o), res ? make_src(*res) : null_src(), res ? 1 : 0, C, T * V, g);
+    tamgcn_note_kernel("gcn_tail_fwd_kernel");
     TG_LAUNCH_CHECK("tamgcn_gcn_tail_fwd");
     return 0;
 }
@@ -204,6 +205,7 @@ extern "C" int tamgcn_gcn_tail_bwd(const float* dg, const float* g, const tamgcn
     TG_CHECK(dg && g && o && o->x1 && o_save && dsum && doz && part && grid_ok(N, C), "tamgcn_gcn_tail_bwd: bad args");
     hipLaunchKernelGGL(gcn_tail_bwd_kernel, dim3(C, N), dim3(EW_THREADS), 0, (hipStream_t)stream,
                        dg, g, make_src(*o), o_save, C, T * V, N, dsum, doz, part);
+    tamgcn_note_kernel("gcn_tail_bwd_kernel");
     TG_LAUNCH_CHECK("tamgcn_gcn_tail_bwd");
     return 0;
 }
@@ -214,6 +216,7 @@ extern "C" int tamgcn_gcn_mid_bwd(const float* dsum, const float* ddiff, const f
     TG_CHECK(dsum && ddiff && y_pre && y_save && dyb && part && grid_ok(N, C) && (!r_pre || r_save), "tamgcn_gcn_mid_bwd: bad args");
     hipLaunchKernelGGL(gcn_mid_bwd_kernel, dim3(C, N), dim3(EW_THREADS), 0, (hipStream_t)stream,
                        dsum, ddiff, y_pre, y_save, r_pre, r_save, C, T * V, N, dyb, dres, part);
+    tamgcn_note_kernel("gcn_mid_bwd_kernel");
     TG_LAUNCH_CHECK("tamgcn_gcn_mid_bwd");
     return 0;
 }
@@ -224,6 +227,7 @@ extern "C" int tamgcn_maxpool_fwd(const tamgcn_src* src, int N, int C, int T_in,
     TG_CHECK(T_out == (T_in + 2 - 3) / stride + 1, "tamgcn_maxpool_fwd: T_out=%d inconsistent with T_in=%d stride=%d", T_out, T_in, stride);
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(C, N), dim3(EW_THREADS), 0, (hipStream_t)stream,
                        make_src(*src), C, T_in, V, stride, y, yctot, ycoff, T_out, N, stats_part);
+    tamgcn_note_kernel("maxpool_fwd_kernel");
     TG_LAUNCH_CHECK("tamgcn_maxpool_fwd");
     return 0;
 }
@@ -233,6 +237,7 @@ extern "C" int tamgcn_maxpool_bwd(const tamgcn_src* gy, const tamgcn_src* src, c
     TG_CHECK(gy && src && gy->x1 && src->x1 && src_save && d && grid_ok(N, C) && stride >= 1, "tamgcn_maxpool_bwd: bad args");
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(C, N), dim3(EW_THREADS), 0, (hipStream_t)stream,
                        make_src(*gy), make_src(*src), src_save, C, T_in, T_out, V, stride, d, dctot, dcoff, N, part);
+    tamgcn_note_kernel("maxpool_bwd_kernel");
     TG_LAUNCH_CHECK("tamgcn_maxpool_bwd");
     return 0;
 }
@@ -242,6 +247,7 @@ extern "C" int tamgcn_add_act_fwd(const tamgcn_src* a, const tamgcn_src* res, in
     TG_CHECK(a && a->x1 && out && grid_ok(N, C), "tamgcn_add_act_fwd: bad args");
     hipLaunchKernelGGL(add_act_fwd_kernel, dim3(C, N), dim3(EW_THREADS), 0, (hipStream_t)stream,
                        make_src(*a), res ? make_src(*res) : null_src(), res ? 1 : 0, relu, C, T * V, out);
+    tamgcn_note_kernel("add_act_fwd_kernel");
     TG_LAUNCH_CHECK("tamgcn_add_act_fwd");
     return 0;
 }
@@ -252,6 +258,7 @@ extern "C" int tamgcn_add_act_bwd(const float* dout, const float* out, int relu,
     TG_CHECK(dout && part && grid_ok(N, C) && (!relu || out) && (!a_pre || a_save) && (!r_pre || r_save), "tamgcn_add_act_bwd: bad args");
     hipLaunchKernelGGL(add_act_bwd_kernel, dim3(C, N), dim3(EW_THREADS), 0, (hipStream_t)stream,
                        dout, out, relu, a_pre, a_save, r_pre, r_save, C, T * V, N, dz, part);
+    tamgcn_note_kernel("add_act_bwd_kernel");
     TG_LAUNCH_CHECK("tamgcn_add_act_bwd");
     return 0;
 }
@@ -260,6 +267,7 @@ extern "C" int tamgcn_apply(const tamgcn_src* src, int N, int C, int T, int V, f
     TG_CHECK(src && src->x1 && y && grid_ok(N, C), "tamgcn_apply: bad args");
     hipLaunchKernelGGL(apply_kernel, dim3(C, N), dim3(EW_THREADS), 0, (hipStream_t)stream,
                        make_src(*src), T * V, y, yctot, ycoff);
+    tamgcn_note_kernel("apply_kernel");
     TG_LAUNCH_CHECK("tamgcn_apply");
     return 0;
 }
@@ -269,6 +277,7 @@ extern "C" int tamgcn_tmean(const tamgcn_src* src, int N, int C, int T, int V, f
     int cpb = EW_THREADS / V;
     hipLaunchKernelGGL(tmean_kernel, dim3(ceil_div(C, cpb), N), dim3(EW_THREADS), 0, (hipStream_t)stream,
                        make_src(*src), N, C, T, V, xbar);
+    tamgcn_note_kernel("tmean_kernel");
     TG_LAUNCH_CHECK("tamgcn_tmean");
     return 0;
 }
