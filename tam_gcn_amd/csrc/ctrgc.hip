@@ -70,6 +70,36 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return 1.f - __fdividef(2.f, e + 1.f);
 }
 
+
+// D[r][u*V+v] = tanh(p[r][u] - q[r][v]) for rel-channels r0..r0+rc-1 of subset s, sample n.
+// Four independent (p, q) pairs are in flight per thread so the L2 latency is paid once per
+// batch, not once per element.
+template <class G>
+__device__ __forceinline__ void fill_D(const CtrgcArgs& a, int n, int s, int r0, int rc, float* Dbuf) {
+    constexpr int V = G::V, VV = G::VV, NT = G::NT;
+    const long long NV = (long long)a.N * V;
+    const float* pb = a.pq + ((long long)(s * 2 + 0) * a.R + r0) * NV + (long long)n * V;
+    const float* qb = a.pq + ((long long)(s * 2 + 1) * a.R + r0) * NV + (long long)n * V;
+    const int total = rc * VV;
+    for (int e0 = threadIdx.x; e0 < total; e0 += 4 * NT) {
+        float pv[4], qv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int e = e0 + i * NT;
+            int ec = e < total ? e : 0;
+            int r = ec / VV, uv = ec - r * VV;
+            int u = uv / V, v = uv - u * V;
+            pv[i] = pb[r * NV + u];
+            qv[i] = qb[r * NV + v];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int e = e0 + i * NT;
+            if (e < total) Dbuf[e] = fast_tanh(pv[i] - qv[i]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // E tiles.  Es[s][c][u*V+v] (or transposed [v*V+u]).  Dbuf is scratch of `region` floats.
 // D chunk [rc][VV] -> LDS, then E(16 x VV) += W4(16 x rc) . D  on MFMA (rows = channels).
@@ -88,13 +118,7 @@ __device__ void build_E(const CtrgcArgs& a, int n, int c0, float* Es, float* Dbu
         for (int r0 = 0; r0 < a.R; r0 += RC) {
             const int rc = min(RC, a.R - r0);
             __syncthreads();
-            for (int e = tid; e < rc * VV; e += NT) {
-                int r = e / VV, uv = e - r * VV;
-                int u = uv / V, v = uv - u * V;
-                float p = a.pq[((long long)(s * 2 + 0) * a.R + r0 + r) * NV + (long long)n * V + u];
-                float q = a.pq[((long long)(s * 2 + 1) * a.R + r0 + r) * NV + (long long)n * V + v];
-                Dbuf[e] = fast_tanh(p - q);
-            }
+            fill_D<G>(a, n, s, r0, rc, Dbuf);
             __syncthreads();
             const float* w4 = a.w4 + ((long long)s * a.Cout + c0 + j) * a.R + r0 + kq;
             const bool last = r0 + rc >= a.R;
@@ -159,7 +183,16 @@ __device__ void x3_chunk(const CtrgcArgs& a, int n, int c0, int t0, int bt, floa
     }
     float4 rv[G::VEC ? NPF : 1];
     float rs[G::VEC ? 1 : NPF];
+    constexpr int NAF = (ST * 16 * SBK + NT - 1) / NT;            // weight-tile values per thread
+    float wv[NAF];
     auto prefetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NAF; ++i) {
+            int e = tid + i * NT;
+            int kk = e & (SBK - 1), row = e >> 5;
+            int sidx = row >> 4, c = row & 15, k = k0 + kk;
+            wv[i] = (row < ST * 16 && k < a.Cin) ? a.w3[((long long)sidx * a.Cout + c0 + c) * a.Cin + k] : 0.f;
+        }
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
             const int k = k0 + p_kk[i];
@@ -175,10 +208,11 @@ __device__ void x3_chunk(const CtrgcArgs& a, int n, int c0, int t0, int bt, floa
     prefetch(0);
     for (int k0 = 0; k0 < a.Cin; k0 += SBK) {
         __syncthreads();                               // previous users of the region are done
-        for (int e = tid; e < ST * 16 * SBK; e += NT) {
-            int kk = e & (SBK - 1), i = e >> 5;
-            int s = i >> 4, c = i & 15, k = k0 + kk;
-            As[i * SBKP + kk] = (k < a.Cin) ? a.w3[((long long)s * a.Cout + c0 + c) * a.Cin + k] : 0.f;
+#pragma unroll
+        for (int i = 0; i < NAF; ++i) {
+            int e = tid + i * NT;
+            int kk = e & (SBK - 1), row = e >> 5;
+            if (row < ST * 16) As[row * SBKP + kk] = wv[i];
         }
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
@@ -267,6 +301,58 @@ __device__ __forceinline__ void aggregate(const float* Mc, const float* inrow, i
     }
 }
 
+
+// dy chunk [CT][ncols] of frames [t0, t0+bt): loads (with the BatchNorm-backward prologue operands)
+// go to registers first, commit() applies the prologue and stores to LDS.  NDY vectors per thread.
+template <class G>
+struct DyTile {
+    static constexpr int VECW = G::VEC ? 4 : 1;
+    static constexpr int ROWV = G::NCOLS / VECW;
+    static constexpr int NDY = (CT * ROWV + G::NT - 1) / G::NT;
+    float v1[NDY][VECW], v2[NDY][VECW], c1[NDY], c2[NDY], c0[NDY];
+
+    __device__ __forceinline__ void load(const SrcDev& dy, int n, int c0ch, int T, int t0, int bt) {
+        constexpr int V = G::V;
+        const int ncols = bt * V;
+        const long long cs = (long long)T * V;
+#pragma unroll
+        for (int i = 0; i < NDY; ++i) {
+            int e = threadIdx.x + i * G::NT;
+            int row = e / ROWV, pos = (e - row * ROWV) * VECW;
+            bool ok = row < CT && pos < ncols;
+            int ch = dy.coff + c0ch + (ok ? row : 0);
+            long long g = ((long long)n * dy.ctot + ch) * cs + (long long)t0 * V + (ok ? pos : 0);
+            c1[i] = dy.coef ? dy.coef[ch] : 1.f;
+            c2[i] = (dy.coef && dy.x2) ? dy.coef[dy.ctot + ch] : 0.f;
+            c0[i] = dy.coef ? dy.coef[2 * dy.ctot + ch] : 0.f;
+            if constexpr (G::VEC) {
+                float4 a4 = ok ? *reinterpret_cast<const float4*>(dy.x1 + g) : make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 b4 = (ok && dy.x2) ? *reinterpret_cast<const float4*>(dy.x2 + g) : make_float4(0.f, 0.f, 0.f, 0.f);
+                v1[i][0] = a4.x; v1[i][1] = a4.y; v1[i][2] = a4.z; v1[i][3] = a4.w;
+                v2[i][0] = b4.x; v2[i][1] = b4.y; v2[i][2] = b4.z; v2[i][3] = b4.w;
+            } else {
+                v1[i][0] = ok ? dy.x1[g] : 0.f;
+                v2[i][0] = (ok && dy.x2) ? dy.x2[g] : 0.f;
+            }
+        }
+    }
+    __device__ __forceinline__ void commit(const SrcDev& dy, float* Zs) {
+#pragma unroll
+        for (int i = 0; i < NDY; ++i) {
+            int e = threadIdx.x + i * G::NT;
+            int row = e / ROWV, pos = (e - row * ROWV) * VECW;
+            if (row < CT) {
+#pragma unroll
+                for (int k = 0; k < VECW; ++k) {
+                    float v = fmaf(c1[i], v1[i][k], fmaf(c2[i], v2[i][k], c0[i]));
+                    if (dy.act == 1) v = fmaxf(v, 0.f);
+                    Zs[row * G::NCOLS + pos + k] = v;
+                }
+            }
+        }
+    }
+};
+
 // ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
@@ -353,17 +439,15 @@ __global__ __launch_bounds__(G::NT) void ctrgc_bwd_dx3_kernel(const CtrgcArgs a,
     float sb[ST];
 #pragma unroll
     for (int s = 0; s < ST; ++s) sb[s] = 0.f;
-    const long long dcs = (long long)a.T * V;
+    DyTile<G> dyt;
+    dyt.load(dy, n, c0, a.T, 0, min(G::BT, a.T));
     for (int t0 = 0; t0 < a.T; t0 += G::BT) {
         const int bt = min(G::BT, a.T - t0);
         const int ncols = bt * V;
         __syncthreads();
-        {
-            int ch = dy.coff + c0 + c;
-            long long base = ((long long)n * dy.ctot + ch) * dcs + (long long)t0 * V;
-            for (int p = lrow; p < ncols; p += G::NTQ * 4) Zs[c * G::NCOLS + p] = src_value(dy, base + p, ch);
-        }
+        dyt.commit(dy, Zs);
         __syncthreads();
+        if (t0 + G::BT < a.T) dyt.load(dy, n, c0, a.T, t0 + G::BT, min(G::BT, a.T - t0 - G::BT));   // next chunk in flight
         if (tq * TB < bt) {
 #pragma unroll
             for (int s = 0; s < ST; ++s) {
@@ -410,9 +494,13 @@ __global__ __launch_bounds__(G::NT) void ctrgc_bwd_dx3_kernel(const CtrgcArgs a,
 template <class G, int ST>
 __global__ __launch_bounds__(G::NT) void ctrgc_bwd_de_kernel(const CtrgcArgs a, const SrcDev dy, float* dA_part, float* dw4_part,
                                                              float* db4_part, float* dalpha_part, float* dpq) {
-    constexpr int V = G::V, VV = G::VV, UB5 = G::UB5, NT = G::NT;
-    constexpr int NOWN = ST * CT * 5;                  // dE owners per frame-half
-    constexpr int NH = NT / NOWN >= 2 ? 2 : 1;         // frame halves handled by different owner groups
+    constexpr int V = G::V, VV = G::VV, NT = G::NT;
+    // dE ownership: thread -> (s, c, group of UBG joints); every owner walks all frames of a chunk
+    constexpr int NUG0 = (NT / (ST * CT)) < V ? (NT / (ST * CT)) : V;
+    constexpr int UBG = (V + NUG0 - 1) / NUG0;         // joints per owner (2 for V=20,S=3 on 512 threads)
+    constexpr int NUG = (V + UBG - 1) / UBG;           // joint groups
+    constexpr int NOWN = ST * CT * NUG;
+    static_assert(NOWN <= NT, "not enough threads for the dE owners");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float red_alpha[16];
     int n, c0;
@@ -421,38 +509,39 @@ __global__ __launch_bounds__(G::NT) void ctrgc_bwd_de_kernel(const CtrgcArgs a, 
     float* X3 = DE + ST * CT * VV;                     // x3 tile / later D scratch
     float* Zs = X3 + a.regionB;                        // dy chunk [CT][NCOLS]
     const int tid = threadIdx.x;
-    const int lrow = tid % (G::NTQ * 4), crow = tid / (G::NTQ * 4);
-    // dE ownership: thread -> (half, s, c, u-group of UB5 joints)
-    const int own_h = tid / NOWN, orem = tid % NOWN;
-    const int own_s = orem / (CT * 5), own_c = (orem / 5) % CT, own_g = orem % 5;
-    const bool owner = own_h < NH;
-    float dE[UB5][V];
+    const int own_s = tid / (CT * NUG), own_c = (tid / NUG) % CT, own_g = tid % NUG;
+    const bool owner = tid < NOWN;
+    float dE[UBG][V];
 #pragma unroll
-    for (int i = 0; i < UB5; ++i)
+    for (int i = 0; i < UBG; ++i)
 #pragma unroll
         for (int v = 0; v < V; ++v) dE[i][v] = 0.f;
 
-    const long long dcs = (long long)a.T * V;
+    DyTile<G> dyt;
     for (int t0 = 0; t0 < a.T; t0 += G::BT) {
         const int bt = min(G::BT, a.T - t0);
-        const int ncols = bt * V;
+        dyt.load(dy, n, c0, a.T, t0, bt);              // in flight under the x3 GEMM below
         x3_chunk<G, ST>(a, n, c0, t0, bt, X3);         // begins with a barrier: previous chunk fully consumed
-        {
-            int ch = dy.coff + c0 + crow;
-            long long base = ((long long)n * dy.ctot + ch) * dcs + (long long)t0 * V;
-            for (int p = lrow; p < ncols; p += G::NTQ * 4) Zs[crow * G::NCOLS + p] = src_value(dy, base + p, ch);
-        }
+        dyt.commit(dy, Zs);
         __syncthreads();
         if (owner) {
             const float* xr = X3 + (own_s * 16 + own_c) * G::PX3;
             const float* dr = Zs + own_c * G::NCOLS;
-            for (int tl = own_h; tl < bt; tl += NH) {
+            for (int tl = 0; tl < bt; ++tl) {
                 float xv[V];
+                if constexpr (V % 4 == 0) {
 #pragma unroll
-                for (int v = 0; v < V; ++v) xv[v] = xr[tl * V + v];
+                    for (int v = 0; v < V; v += 4) {
+                        f32x4 t = *reinterpret_cast<const f32x4*>(xr + tl * V + v);
+                        xv[v] = t[0]; xv[v + 1] = t[1]; xv[v + 2] = t[2]; xv[v + 3] = t[3];
+                    }
+                } else {
 #pragma unroll
-                for (int i = 0; i < UB5; ++i) {
-                    int u = own_g * UB5 + i;
+                    for (int v = 0; v < V; ++v) xv[v] = xr[tl * V + v];
+                }
+#pragma unroll
+                for (int i = 0; i < UBG; ++i) {
+                    int u = own_g * UBG + i;
                     float d = (u < V) ? dr[tl * V + u] : 0.f;
 #pragma unroll
                     for (int v = 0; v < V; ++v) dE[i][v] = fmaf(d, xv[v], dE[i][v]);
@@ -461,22 +550,17 @@ __global__ __launch_bounds__(G::NT) void ctrgc_bwd_de_kernel(const CtrgcArgs a, 
         }
     }
     __syncthreads();
-    for (int h = 0; h < NH; ++h) {                     // fixed order => deterministic
-        if (owner && own_h == h) {
+    if (owner) {
 #pragma unroll
-            for (int i = 0; i < UB5; ++i) {
-                int u = own_g * UB5 + i;
-                if (u < V) {
+        for (int i = 0; i < UBG; ++i) {
+            int u = own_g * UBG + i;
+            if (u < V) {
 #pragma unroll
-                    for (int v = 0; v < V; ++v) {
-                        float* d = &DE[(own_s * CT + own_c) * VV + u * V + v];
-                        *d = (h == 0 ? 0.f : *d) + dE[i][v];
-                    }
-                }
+                for (int v = 0; v < V; ++v) DE[(own_s * CT + own_c) * VV + u * V + v] = dE[i][v];
             }
         }
-        __syncthreads();
     }
+    __syncthreads();
     // (a) dA partial: sum over this block's channels
     {
         const int blk = n * a.nct + c0 / CT;
@@ -511,13 +595,7 @@ __global__ __launch_bounds__(G::NT) void ctrgc_bwd_de_kernel(const CtrgcArgs a, 
         for (int r0 = 0; r0 < a.R; r0 += RC) {
             const int rc = min(RC, a.R - r0);
             __syncthreads();
-            for (int e = tid; e < rc * VV; e += NT) {
-                int r = e / VV, uv = e - r * VV;
-                int u = uv / V, v = uv - u * V;
-                float p = a.pq[((long long)(s * 2 + 0) * a.R + r0 + r) * NV + (long long)n * V + u];
-                float q = a.pq[((long long)(s * 2 + 1) * a.R + r0 + r) * NV + (long long)n * V + v];
-                X3[e] = fast_tanh(p - q);
-            }
+            fill_D<G>(a, n, s, r0, rc, X3);
             __syncthreads();
             if (rowthr) {
                 // dW4raw[c][r] = sum_uv dE[c][uv] * D[r][uv]

@@ -9,10 +9,58 @@ Reference arithmetic being reproduced: models/ctrgcn.py:52-69 (TemporalConv),
 :72-147 (MultiScale_TemporalConv), :150-177 (CTRGC), :179-193 (unit_tcn),
 :196-263 (unit_gcn), :266-284 (TCN_GCN_unit).
 """
+import contextlib
+import os
+
 import torch
 
 from . import ops
 from .ops import S, RELU
+
+
+# ---------------------------------------------------------------------------
+# Side streams.  Weight-gradient kernels are off the backward critical path and the TCN
+# branches are mutually independent; most of these kernels are latency-bound with 1-2
+# workgroups per CU, so letting them overlap raises utilisation.  fork()/join() use
+# wait_stream (event record + wait), which HIP graph capture turns into parallel branches.
+# ---------------------------------------------------------------------------
+_SIDE = {}
+USE_SIDE_STREAMS = os.environ.get('TAMGCN_SIDE_STREAMS', '1') != '0'
+
+
+class Fork:
+    """with Fork(device, k) as f:  f.on(i) -> context running on side stream i; joins on exit."""
+
+    def __init__(self, device, k=2):
+        self.main = torch.cuda.current_stream(device)
+        key = (device.index, k)
+        if key not in _SIDE:
+            _SIDE[key] = [torch.cuda.Stream(device) for _ in range(k)]
+        self.side = _SIDE[key] if USE_SIDE_STREAMS else []
+        self.used = set()
+
+    def on(self, i):
+        if not self.side:
+            return contextlib.nullcontext()
+        st = self.side[i % len(self.side)]
+        if i % len(self.side) not in self.used:
+            st.wait_stream(self.main)                  # fork: everything enqueued so far on main is visible
+            self.used.add(i % len(self.side))
+        return torch.cuda.stream(st)
+
+    def refork(self):
+        """Call after enqueuing more work on main that later side work depends on."""
+        for i in self.used:
+            self.side[i].wait_stream(self.main)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        for i in self.used:
+            self.main.wait_stream(self.side[i])        # join
+        self.used.clear()
+        return False
 
 
 class BN:
@@ -56,6 +104,14 @@ def gcn_forward(x, P, training, save):
     S_, R, Cout = P.S, P.R, P.Cout
     count = N * T * V
     xs = S(x)
+    fk = Fork(x.device, 2)
+    fk.__enter__()
+    d_pre = coef_d = save_d = None
+    if P.mode == 'conv':                               # independent of the CTRGC chain: side stream
+        with fk.on(0):
+            d_pre, dpart = ops.conv(xs, K=Cin, w=P.Wd, bias=P.bd, M=Cout, stats=training)
+            coef_d, save_d = _coef(Cout, x)
+            P.bnd.fwd(dpart, 0, count, training, coef_d, save_d, 0)
     # pooled joint embeddings (conv1/conv2 commute with the mean over T)
     xbar = ops.tmean(xs, Cin)                                             # (Cin, N, V)
     pq, _ = ops.conv(S(xbar.view(1, Cin, N, V)), K=Cin, w=P.W12, bias=P.B12, M=S_ * 2 * R)
@@ -63,11 +119,8 @@ def gcn_forward(x, P, training, save):
     y_pre, ypart = ops.ctrgc_fwd(xs, pq, P.W3, P.B3, P.W4, P.B4, P.PA, P.alpha, Cin, Cout, S_, R, stats=training)
     coef_y, save_y = _coef(Cout, x)
     P.bn.fwd(ypart, 0, count, training, coef_y, save_y, 0)
-    d_pre = coef_d = save_d = None
+    fk.__exit__()                                      # join: d_pre and its coefficients are needed now
     if P.mode == 'conv':
-        d_pre, dpart = ops.conv(xs, K=Cin, w=P.Wd, bias=P.bd, M=Cout, stats=training)
-        coef_d, save_d = _coef(Cout, x)
-        P.bnd.fwd(dpart, 0, count, training, coef_d, save_d, 0)
         res = S(d_pre, coef=coef_d)
         coef_diff = torch.stack((coef_d[0], -coef_y[0], coef_d[2] - coef_y[2]))
         diff = S(d_pre, y_pre, coef_diff)
@@ -99,6 +152,8 @@ def gcn_backward(P, sv, dg, need_dx=True, extra_dx=None):
     S_, R, Cout = P.S, P.R, P.Cout
     count = N * T * V
     G = {}
+    fk = Fork(x.device, 2)
+    fk.__enter__()
     # tail: relu, tanh(BN(offset conv))
     dsum, doz, part_o = ops.gcn_tail_bwd(dg, g, S(o_pre, coef=sv['coef_o']), sv['save_o'])
     coefb_o = torch.empty(3, Cout, device=x.device)
@@ -111,7 +166,8 @@ def gcn_backward(P, sv, dg, need_dx=True, extra_dx=None):
         diff = S(x, y_pre, sv['coef_diff'])
     else:
         diff = S(y_pre, None, sv['coef_diff'])
-    G['Wo'] = ops.wgrad(gyo, diff, M=Cout, K=Cout)
+    with fk.on(0):
+        G['Wo'] = ops.wgrad(gyo, diff, M=Cout, K=Cout)
     dyb, dres, part2 = ops.gcn_mid_bwd(dsum, ddiff, y_pre, sv['save_y'], d_pre if P.mode == 'conv' else None,
                                        sv['save_d'], want_dres=P.mode != 'zero')
     coefb_y = torch.empty(3, Cout, device=x.device)
@@ -122,9 +178,12 @@ def gcn_backward(P, sv, dg, need_dx=True, extra_dx=None):
     dx3, G['B3'], G['PA'], G['W4'], G['B4'], G['alpha'], dpq = ops.ctrgc_bwd(
         xs, pq, P.W3, P.B3, P.W4, P.B4, P.PA, P.alpha, Cin, Cout, S_, R, dy)
     dpq4 = S(dpq.view(1, S_ * 2 * R, N, V))
-    G['W12'] = ops.wgrad(dpq4, S(xbar.view(1, Cin, N, V)), M=S_ * 2 * R, K=Cin)
-    G['B12'] = dpq.sum((1, 2))
-    G['W3'] = ops.wgrad(S(dx3), xs, M=S_ * Cout, K=Cin)
+    fk.refork()                                        # dx3 / dpq are ready on main
+    with fk.on(1):
+        G['W3'] = ops.wgrad(S(dx3), xs, M=S_ * Cout, K=Cin)
+    with fk.on(0):
+        G['W12'] = ops.wgrad(dpq4, S(xbar.view(1, Cin, N, V)), M=S_ * 2 * R, K=Cin)
+        G['B12'] = dpq.sum((1, 2))
     dx = None
     if need_dx:
         dxbar, _ = ops.conv(dpq4, K=S_ * 2 * R, w=P.W12, bias=None, M=Cin, wmode=1)        # (1, Cin, N, V)
@@ -136,9 +195,12 @@ def gcn_backward(P, sv, dg, need_dx=True, extra_dx=None):
         G['bnd.w'], G['bnd.b'], G['bd'] = P.bnd.bwd(part2[2:4], 0, count, sv['save_d'], 0, training, coefb_d, 0,
                                                      want_dbias=True)
         gyd = S(dres, d_pre, coefb_d)
+        fk.refork()
+        with fk.on(0):
+            G['Wd'] = ops.wgrad(gyd, xs, M=Cout, K=Cin)
         if need_dx:
             ops.conv(gyd, K=Cout, w=P.Wd, bias=None, M=Cin, wmode=1, add1=dx, y=dx)
-        G['Wd'] = ops.wgrad(gyd, xs, M=Cout, K=Cin)
+    fk.__exit__()
     return dx, G
 
 
@@ -168,22 +230,29 @@ def tcn_forward(g, P, training, save, xres=None):
     cnt1, cnt2 = N * T * V, N * T2 * V
     gs = S(g)
     Ch = (nb + 1) * Cb
+    fk = Fork(g.device, 2)
+    fk.__enter__()
+    cat_pre = torch.empty(N, Cout, T2, V, device=g.device)
+    coef_c, save_c = _coef(Cout, g)
+    with fk.on(1):                                     # the plain 1x1 branch only needs g
+        _, lpart = ops.conv(gs, K=Cin, w=P.Wl, bias=P.bl, M=Cb, stride=s, y=cat_pre, ycoff=(nb + 1) * Cb, T_out=T2,
+                            stats=training)
+        P.bn_l.fwd(lpart, (nb + 1) * Cb, cnt2, training, coef_c, save_c, (nb + 1) * Cb)
     h_pre, hpart = ops.conv(gs, K=Cin, w=P.Win, bias=P.bin, M=Ch, stats=training)
     coef_h, save_h = _coef(Ch, g)
     for b in range(nb + 1):
         P.bn_in[b].fwd(hpart, b * Cb, cnt1, training, coef_h, save_h, b * Cb)
-    cat_pre = torch.empty(N, Cout, T2, V, device=g.device)
-    coef_c, save_c = _coef(Cout, g)
+    fk.refork()                                        # h_pre and coef_h are ready on main
     for b in range(nb):
         k, d = P.ks[b], P.dils[b]
-        _, part = ops.conv(S(h_pre, coef=coef_h, coff=b * Cb, act=RELU), K=Cb, w=P.Wt[b], bias=P.bt[b], M=Cb,
-                           KT=k, dil=d, stride=s, pad=_tpad(k, d), y=cat_pre, ycoff=b * Cb, T_out=T2, stats=training)
-        P.bn_t[b].fwd(part, b * Cb, cnt2, training, coef_c, save_c, b * Cb)
-    part = ops.maxpool_fwd(S(h_pre, coef=coef_h, coff=nb * Cb, act=RELU), Cb, s, cat_pre, nb * Cb, stats=training)
-    P.bn_pool.fwd(part, nb * Cb, cnt2, training, coef_c, save_c, nb * Cb)
-    _, part = ops.conv(gs, K=Cin, w=P.Wl, bias=P.bl, M=Cb, stride=s, y=cat_pre, ycoff=(nb + 1) * Cb, T_out=T2,
-                       stats=training)
-    P.bn_l.fwd(part, (nb + 1) * Cb, cnt2, training, coef_c, save_c, (nb + 1) * Cb)
+        with (fk.on(b) if b > 0 else contextlib.nullcontext()):        # branch 0 on main, the others beside it
+            _, part = ops.conv(S(h_pre, coef=coef_h, coff=b * Cb, act=RELU), K=Cb, w=P.Wt[b], bias=P.bt[b], M=Cb,
+                               KT=k, dil=d, stride=s, pad=_tpad(k, d), y=cat_pre, ycoff=b * Cb, T_out=T2,
+                               stats=training)
+            P.bn_t[b].fwd(part, b * Cb, cnt2, training, coef_c, save_c, b * Cb)
+    with fk.on(0):
+        part = ops.maxpool_fwd(S(h_pre, coef=coef_h, coff=nb * Cb, act=RELU), Cb, s, cat_pre, nb * Cb, stats=training)
+        P.bn_pool.fwd(part, nb * Cb, cnt2, training, coef_c, save_c, nb * Cb)
     r_pre = coef_r = save_r = None
     if xres is None:
         xres = g
@@ -198,6 +267,7 @@ def tcn_forward(g, P, training, save, xres=None):
         res = S(r_pre, coef=coef_r)
     else:
         res = None
+    fk.__exit__()                                      # join all branches
     out = ops.add_act_fwd(S(cat_pre, coef=coef_c), res, P.relu, Cout)
     sv = None
     if save:
@@ -217,6 +287,8 @@ def tcn_backward(P, sv, dout, need_dg=True, need_dxres=True):
     cnt1, cnt2 = N * T * V, N * T2 * V
     Ch = (nb + 1) * Cb
     G = {}
+    fk = Fork(g.device, 2)
+    fk.__enter__()
     dz, part = ops.add_act_bwd(dout, out, P.relu, cat_pre, sv['save_c'], r_pre, sv['save_r'], want_dz=bool(P.relu))
     if dz is None:
         dz = dout
@@ -248,8 +320,9 @@ def tcn_backward(P, sv, dout, need_dg=True, need_dxres=True):
                          pad=(k - 1) * d - pad, wmode=1, up=s, y=dh, ycoff=b * Cb, T_out=T,
                          mask=S(h_pre, coef=sv['coef_h'], coff=b * Cb), aux=h_pre, aux_center=sv['save_h'], auxcoff=b * Cb,
                          stats=True)
-        G['Wt'].append(ops.wgrad(gcat(b * Cb), S(h_pre, coef=sv['coef_h'], coff=b * Cb, act=RELU), M=Cb, K=Cb,
-                                 KT=k, dil=d, stride=s, pad=pad))
+        with fk.on(b):
+            G['Wt'].append(ops.wgrad(gcat(b * Cb), S(h_pre, coef=sv['coef_h'], coff=b * Cb, act=RELU), M=Cb, K=Cb,
+                                     KT=k, dil=d, stride=s, pad=pad))
         dgam, dbet, dbias = P.bn_in[b].bwd(hp, b * Cb, cnt1, sv['save_h'], b * Cb, training, coefb_h, b * Cb, True)
         G['bn_in'].append((dgam, dbet))
         dbin.append(dbias)
@@ -261,8 +334,11 @@ def tcn_backward(P, sv, dout, need_dg=True, need_dxres=True):
     G['bin'] = torch.cat(dbin)
     gs = S(g)
     gyh = S(dh, h_pre, coefb_h)
-    G['Win'] = ops.wgrad(gyh, gs, M=Ch, K=Cin)
-    G['Wl'] = ops.wgrad(gcat((nb + 1) * Cb), gs, M=Cb, K=Cin, stride=s)
+    fk.refork()                                        # dh and its BN-backward coefficients are ready
+    with fk.on(0):
+        G['Win'] = ops.wgrad(gyh, gs, M=Ch, K=Cin)
+    with fk.on(1):
+        G['Wl'] = ops.wgrad(gcat((nb + 1) * Cb), gs, M=Cb, K=Cin, stride=s)
     dg = None
     if need_dg:
         dg, _ = ops.conv(gyh, K=Ch, w=P.Win, bias=None, M=Cin, wmode=1)
@@ -277,7 +353,9 @@ def tcn_backward(P, sv, dout, need_dg=True, need_dxres=True):
         gyr = S(dz, r_pre, coefb_r)
         rk = P.rk
         rpad = (rk - 1) // 2
-        G['Wr'] = ops.wgrad(gyr, S(xres), M=Cout, K=xres.shape[1], KT=rk, stride=s, pad=rpad)
+        fk.refork()
+        with fk.on(1):
+            G['Wr'] = ops.wgrad(gyr, S(xres), M=Cout, K=xres.shape[1], KT=rk, stride=s, pad=rpad)
         if need_dxres:
             Tx = xres.shape[2]
             if rk == 1:
@@ -286,6 +364,7 @@ def tcn_backward(P, sv, dout, need_dg=True, need_dxres=True):
             else:
                 dxres, _ = ops.conv(gyr, K=Cout, w=P.Wr, bias=None, M=xres.shape[1], KT=rk, stride=1,
                                     pad=(rk - 1) - rpad, wmode=1, up=s, T_out=Tx)
+    fk.__exit__()
     return dg, dxres, G
 
 
