@@ -23,18 +23,59 @@ __device__ __forceinline__ void block_store_sums(const float* vals, int nst, flo
     }
 }
 
+// float4 view of the fused prologue for one channel row (coefficients are per channel)
+struct RowSrc {
+    const float* x1; const float* x2; float c1, c2, c0; int act;
+};
+__device__ __forceinline__ RowSrc row_src(const SrcDev& s, long long base, int ch) {
+    RowSrc r;
+    r.x1 = s.x1 + base; r.x2 = s.x2 ? s.x2 + base : nullptr;
+    r.c1 = s.coef ? s.coef[ch] : 1.f;
+    r.c2 = (s.coef && s.x2) ? s.coef[s.ctot + ch] : 0.f;
+    r.c0 = s.coef ? s.coef[2 * s.ctot + ch] : 0.f;
+    r.act = s.act;
+    return r;
+}
+__device__ __forceinline__ float row_val(const RowSrc& r, int i) {
+    float v = fmaf(r.c1, r.x1[i], fmaf(r.c2, r.x2 ? r.x2[i] : 0.f, r.c0));
+    return r.act == 1 ? fmaxf(v, 0.f) : v;
+}
+__device__ __forceinline__ float4 row_val4(const RowSrc& r, int i4) {
+    float4 a = reinterpret_cast<const float4*>(r.x1)[i4];
+    float4 b = r.x2 ? reinterpret_cast<const float4*>(r.x2)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 o;
+    o.x = fmaf(r.c1, a.x, fmaf(r.c2, b.x, r.c0)); o.y = fmaf(r.c1, a.y, fmaf(r.c2, b.y, r.c0));
+    o.z = fmaf(r.c1, a.z, fmaf(r.c2, b.z, r.c0)); o.w = fmaf(r.c1, a.w, fmaf(r.c2, b.w, r.c0));
+    if (r.act == 1) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    return o;
+}
+// rows are 16-byte aligned iff L % 4 == 0 (allocations are 256-byte aligned)
+#define EW_VEC(L) (((L) & 3) == 0)
+
 // ---- unit_gcn tail -------------------------------------------------------
 __global__ __launch_bounds__(EW_THREADS) void gcn_tail_fwd_kernel(SrcDev y, SrcDev o, SrcDev res, int has_res,
                                                                   int C, int L, float* g) {
     const int c = blockIdx.x, n = blockIdx.y;
-    const long long by = ((long long)n * y.ctot + y.coff + c) * L;
-    const long long bo = ((long long)n * o.ctot + o.coff + c) * L;
-    const long long br = has_res ? ((long long)n * res.ctot + res.coff + c) * L : 0;
+    const RowSrc ry = row_src(y, ((long long)n * y.ctot + y.coff + c) * L, y.coff + c);
+    const RowSrc ro = row_src(o, ((long long)n * o.ctot + o.coff + c) * L, o.coff + c);
+    RowSrc rr = ry;
+    if (has_res) rr = row_src(res, ((long long)n * res.ctot + res.coff + c) * L, res.coff + c);
     float* gp = g + ((long long)n * C + c) * L;
-    for (int i = threadIdx.x; i < L; i += EW_THREADS) {
-        float v = src_value(y, by + i, y.coff + c) + tanhf(src_value(o, bo + i, o.coff + c));
-        if (has_res) v += src_value(res, br + i, res.coff + c);
-        gp[i] = fmaxf(v, 0.f);
+    if (EW_VEC(L)) {
+        for (int i = threadIdx.x; i < (L >> 2); i += EW_THREADS) {
+            float4 a = row_val4(ry, i), b = row_val4(ro, i);
+            float4 r = has_res ? row_val4(rr, i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 v;
+            v.x = fmaxf(a.x + tanhf(b.x) + r.x, 0.f); v.y = fmaxf(a.y + tanhf(b.y) + r.y, 0.f);
+            v.z = fmaxf(a.z + tanhf(b.z) + r.z, 0.f); v.w = fmaxf(a.w + tanhf(b.w) + r.w, 0.f);
+            reinterpret_cast<float4*>(gp)[i] = v;
+        }
+    } else {
+        for (int i = threadIdx.x; i < L; i += EW_THREADS) {
+            float v = row_val(ry, i) + tanhf(row_val(ro, i));
+            if (has_res) v += row_val(rr, i);
+            gp[i] = fmaxf(v, 0.f);
+        }
     }
 }
 
@@ -43,16 +84,34 @@ __global__ __launch_bounds__(EW_THREADS) void gcn_tail_bwd_kernel(const float* d
     const int c = blockIdx.x, n = blockIdx.y;
     const long long b = ((long long)n * C + c) * L;
     const long long bo = ((long long)n * o.ctot + o.coff + c) * L;
+    const RowSrc ro = row_src(o, bo, o.coff + c);
     float s[2] = {0.f, 0.f};
     const float mu = o_save[o.coff + c];
-    for (int i = threadIdx.x; i < L; i += EW_THREADS) {
-        float d = g[b + i] > 0.f ? dg[b + i] : 0.f;
-        float off = tanhf(src_value(o, bo + i, o.coff + c));
-        float dz = d * (1.f - off * off);
-        dsum[b + i] = d;
-        doz[b + i] = dz;
-        s[0] += dz;
-        s[1] = fmaf(dz, o.x1[bo + i] - mu, s[1]);
+    if (EW_VEC(L)) {
+        for (int i = threadIdx.x; i < (L >> 2); i += EW_THREADS) {
+            float4 gg = reinterpret_cast<const float4*>(g + b)[i], dd = reinterpret_cast<const float4*>(dg + b)[i];
+            float4 ob = row_val4(ro, i), op = reinterpret_cast<const float4*>(o.x1 + bo)[i];
+            float4 d, z;
+            float t;
+            d.x = gg.x > 0.f ? dd.x : 0.f; t = tanhf(ob.x); z.x = d.x * (1.f - t * t);
+            d.y = gg.y > 0.f ? dd.y : 0.f; t = tanhf(ob.y); z.y = d.y * (1.f - t * t);
+            d.z = gg.z > 0.f ? dd.z : 0.f; t = tanhf(ob.z); z.z = d.z * (1.f - t * t);
+            d.w = gg.w > 0.f ? dd.w : 0.f; t = tanhf(ob.w); z.w = d.w * (1.f - t * t);
+            reinterpret_cast<float4*>(dsum + b)[i] = d;
+            reinterpret_cast<float4*>(doz + b)[i] = z;
+            s[0] += (z.x + z.y) + (z.z + z.w);
+            s[1] = fmaf(z.x, op.x - mu, fmaf(z.y, op.y - mu, fmaf(z.z, op.z - mu, fmaf(z.w, op.w - mu, s[1]))));
+        }
+    } else {
+        for (int i = threadIdx.x; i < L; i += EW_THREADS) {
+            float d = g[b + i] > 0.f ? dg[b + i] : 0.f;
+            float off = tanhf(row_val(ro, i));
+            float dz = d * (1.f - off * off);
+            dsum[b + i] = d;
+            doz[b + i] = dz;
+            s[0] += dz;
+            s[1] = fmaf(dz, o.x1[bo + i] - mu, s[1]);
+        }
     }
     block_store_sums(s, 2, part, C, N, c, n);
 }
@@ -64,14 +123,32 @@ __global__ __launch_bounds__(EW_THREADS) void gcn_mid_bwd_kernel(const float* ds
     const long long b = ((long long)n * C + c) * L;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     const float muy = y_save[c], mur = r_pre ? r_save[c] : 0.f;
-    for (int i = threadIdx.x; i < L; i += EW_THREADS) {
-        float d = dsum[b + i], dd = ddiff[b + i];
-        float a = d - dd, r = d + dd;
-        dyb[b + i] = a;
-        s[0] += a;
-        s[1] = fmaf(a, y_pre[b + i] - muy, s[1]);
-        if (dres) dres[b + i] = r;
-        if (r_pre) { s[2] += r; s[3] = fmaf(r, r_pre[b + i] - mur, s[3]); }
+    if (EW_VEC(L)) {
+        for (int i = threadIdx.x; i < (L >> 2); i += EW_THREADS) {
+            float4 d = reinterpret_cast<const float4*>(dsum + b)[i], dd = reinterpret_cast<const float4*>(ddiff + b)[i];
+            float4 yp = reinterpret_cast<const float4*>(y_pre + b)[i];
+            float4 rp = r_pre ? reinterpret_cast<const float4*>(r_pre + b)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 a = make_float4(d.x - dd.x, d.y - dd.y, d.z - dd.z, d.w - dd.w);
+            float4 r = make_float4(d.x + dd.x, d.y + dd.y, d.z + dd.z, d.w + dd.w);
+            reinterpret_cast<float4*>(dyb + b)[i] = a;
+            if (dres) reinterpret_cast<float4*>(dres + b)[i] = r;
+            s[0] += (a.x + a.y) + (a.z + a.w);
+            s[1] = fmaf(a.x, yp.x - muy, fmaf(a.y, yp.y - muy, fmaf(a.z, yp.z - muy, fmaf(a.w, yp.w - muy, s[1]))));
+            if (r_pre) {
+                s[2] += (r.x + r.y) + (r.z + r.w);
+                s[3] = fmaf(r.x, rp.x - mur, fmaf(r.y, rp.y - mur, fmaf(r.z, rp.z - mur, fmaf(r.w, rp.w - mur, s[3]))));
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < L; i += EW_THREADS) {
+            float d = dsum[b + i], dd = ddiff[b + i];
+            float a = d - dd, r = d + dd;
+            dyb[b + i] = a;
+            s[0] += a;
+            s[1] = fmaf(a, y_pre[b + i] - muy, s[1]);
+            if (dres) dres[b + i] = r;
+            if (r_pre) { s[2] += r; s[3] = fmaf(r, r_pre[b + i] - mur, s[3]); }
+        }
     }
     block_store_sums(s, r_pre ? 4 : 2, part, C, N, c, n);
 }
@@ -136,13 +213,23 @@ __global__ __launch_bounds__(EW_THREADS) void maxpool_bwd_kernel(SrcDev gy, SrcD
 __global__ __launch_bounds__(EW_THREADS) void add_act_fwd_kernel(SrcDev a, SrcDev res, int has_res, int relu,
                                                                  int C, int L, float* out) {
     const int c = blockIdx.x, n = blockIdx.y;
-    const long long ba = ((long long)n * a.ctot + a.coff + c) * L;
-    const long long br = has_res ? ((long long)n * res.ctot + res.coff + c) * L : 0;
+    const RowSrc ra = row_src(a, ((long long)n * a.ctot + a.coff + c) * L, a.coff + c);
+    RowSrc rr = ra;
+    if (has_res) rr = row_src(res, ((long long)n * res.ctot + res.coff + c) * L, res.coff + c);
     float* op = out + ((long long)n * C + c) * L;
-    for (int i = threadIdx.x; i < L; i += EW_THREADS) {
-        float v = src_value(a, ba + i, a.coff + c);
-        if (has_res) v += src_value(res, br + i, res.coff + c);
-        op[i] = relu ? fmaxf(v, 0.f) : v;
+    if (EW_VEC(L)) {
+        for (int i = threadIdx.x; i < (L >> 2); i += EW_THREADS) {
+            float4 v = row_val4(ra, i);
+            if (has_res) { float4 r = row_val4(rr, i); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            reinterpret_cast<float4*>(op)[i] = v;
+        }
+    } else {
+        for (int i = threadIdx.x; i < L; i += EW_THREADS) {
+            float v = row_val(ra, i);
+            if (has_res) v += row_val(rr, i);
+            op[i] = relu ? fmaxf(v, 0.f) : v;
+        }
     }
 }
 
@@ -154,13 +241,37 @@ __global__ __launch_bounds__(EW_THREADS) void add_act_bwd_kernel(const float* do
     const long long b = ((long long)n * C + c) * L;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     const float mua = a_pre ? a_save[c] : 0.f, mur = r_pre ? r_save[c] : 0.f;
-    for (int i = threadIdx.x; i < L; i += EW_THREADS) {
-        float d = dout[b + i];
-        if (relu && !(out[b + i] > 0.f)) d = 0.f;
-        if (dz) dz[b + i] = d;
-        s[0] += d;
-        if (a_pre) s[1] = fmaf(d, a_pre[b + i] - mua, s[1]);
-        if (r_pre) { s[2] += d; s[3] = fmaf(d, r_pre[b + i] - mur, s[3]); }
+    if (EW_VEC(L)) {
+        for (int i = threadIdx.x; i < (L >> 2); i += EW_THREADS) {
+            float4 d = reinterpret_cast<const float4*>(dout + b)[i];
+            if (relu) {
+                float4 o = reinterpret_cast<const float4*>(out + b)[i];
+                if (!(o.x > 0.f)) d.x = 0.f;
+                if (!(o.y > 0.f)) d.y = 0.f;
+                if (!(o.z > 0.f)) d.z = 0.f;
+                if (!(o.w > 0.f)) d.w = 0.f;
+            }
+            if (dz) reinterpret_cast<float4*>(dz + b)[i] = d;
+            s[0] += (d.x + d.y) + (d.z + d.w);
+            if (a_pre) {
+                float4 p = reinterpret_cast<const float4*>(a_pre + b)[i];
+                s[1] = fmaf(d.x, p.x - mua, fmaf(d.y, p.y - mua, fmaf(d.z, p.z - mua, fmaf(d.w, p.w - mua, s[1]))));
+            }
+            if (r_pre) {
+                float4 p = reinterpret_cast<const float4*>(r_pre + b)[i];
+                s[2] += (d.x + d.y) + (d.z + d.w);
+                s[3] = fmaf(d.x, p.x - mur, fmaf(d.y, p.y - mur, fmaf(d.z, p.z - mur, fmaf(d.w, p.w - mur, s[3]))));
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < L; i += EW_THREADS) {
+            float d = dout[b + i];
+            if (relu && !(out[b + i] > 0.f)) d = 0.f;
+            if (dz) dz[b + i] = d;
+            s[0] += d;
+            if (a_pre) s[1] = fmaf(d, a_pre[b + i] - mua, s[1]);
+            if (r_pre) { s[2] += d; s[3] = fmaf(d, r_pre[b + i] - mur, s[3]); }
+        }
     }
     block_store_sums(s, r_pre ? 4 : 2, part, C, N, c, n);
 }

@@ -53,6 +53,11 @@ class Fork:
         for i in self.used:
             self.side[i].wait_stream(self.main)
 
+    def join(self, i):
+        """main waits for side stream i now (its results are needed on main)."""
+        if self.side and (i % len(self.side)) in self.used:
+            self.main.wait_stream(self.side[i % len(self.side)])
+
     def __enter__(self):
         return self
 
@@ -175,18 +180,23 @@ def gcn_backward(P, sv, dg, need_dx=True, extra_dx=None):
     dy = S(dyb, y_pre, coefb_y)
     # CTRGC
     xs = S(x)
-    dx3, G['B3'], G['PA'], G['W4'], G['B4'], G['alpha'], dpq = ops.ctrgc_bwd(
-        xs, pq, P.W3, P.B3, P.W4, P.B4, P.PA, P.alpha, Cin, Cout, S_, R, dy)
-    dpq4 = S(dpq.view(1, S_ * 2 * R, N, V))
-    fk.refork()                                        # dx3 / dpq are ready on main
-    with fk.on(1):
-        G['W3'] = ops.wgrad(S(dx3), xs, M=S_ * Cout, K=Cin)
-    with fk.on(0):
+    cargs = (xs, pq, P.W3, P.B3, P.W4, P.B4, P.PA, P.alpha, Cin, Cout, S_, R, dy)
+    fk.refork()                                        # dyb / coefb_y are ready on main
+    with fk.on(1):                                     # the dE chain runs beside the dx3 -> dx chain
+        G['PA'], G['W4'], G['B4'], G['alpha'], dpq = ops.ctrgc_bwd_de(*cargs)
+        dpq4 = S(dpq.view(1, S_ * 2 * R, N, V))
         G['W12'] = ops.wgrad(dpq4, S(xbar.view(1, Cin, N, V)), M=S_ * 2 * R, K=Cin)
         G['B12'] = dpq.sum((1, 2))
+        dxbar = None
+        if need_dx:
+            dxbar, _ = ops.conv(dpq4, K=S_ * 2 * R, w=P.W12, bias=None, M=Cin, wmode=1)    # (1, Cin, N, V)
+    dx3, G['B3'] = ops.ctrgc_bwd_dx3(*cargs)
+    fk.refork()
+    with fk.on(0):
+        G['W3'] = ops.wgrad(S(dx3), xs, M=S_ * Cout, K=Cin)
+    fk.join(1)                                         # dxbar feeds the dx conv
     dx = None
     if need_dx:
-        dxbar, _ = ops.conv(dpq4, K=S_ * 2 * R, w=P.W12, bias=None, M=Cin, wmode=1)        # (1, Cin, N, V)
         dx, _ = ops.conv(S(dx3), K=S_ * Cout, w=P.W3, bias=None, M=Cin, wmode=1,
                          bcast=dxbar.view(Cin, N, V), bcast_scale=1.0 / T,
                          add1=dres if P.mode == 'identity' else None, add2=extra_dx)

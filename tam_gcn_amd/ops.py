@@ -176,27 +176,41 @@ def ctrgc_fwd(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, stats):
     return y, part
 
 
-def ctrgc_bwd(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy):
-    """Returns dx3 (N,S*Cout,T,V), db3 [S*Cout], dA [S,V,V], dw4 [S,Cout,R], db4 [S,Cout], dalpha [1], dpq [S*2*R,N,V]."""
+def ctrgc_bwd_dx3(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy):
+    """dx3 (N,S*Cout,T,V) = E^T . dy, and db3 [S*Cout]."""
     N, _, T, V = x.x1.shape
-    lib = _lib_()
+    d = _ctrgc_desc(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R)
+    dyc = dy.c()
+    dx3 = empty(N, S * Cout, T, V, like=x.x1)
+    db3_part = empty(N, S * Cout, like=x.x1)
+    _lib.check(_lib_().tamgcn_ctrgc_bwd_dx3(C.byref(d), C.byref(dyc), _ptr(dx3), _ptr(db3_part), _stream()),
+               'tamgcn_ctrgc_bwd_dx3')
+    return dx3, reduce_sum(db3_part, N)
+
+
+def ctrgc_bwd_de(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy):
+    """The dE chain: dA [S,V,V], dw4 [S,Cout,R], db4 [S,Cout], dalpha [1], dpq [S*2*R,N,V]."""
+    N, _, T, V = x.x1.shape
     d = _ctrgc_desc(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R)
     dyc = dy.c()
     like = x.x1
-    dx3 = empty(N, S * Cout, T, V, like=like)
-    db3_part = empty(N, S * Cout, like=like)
-    _lib.check(lib.tamgcn_ctrgc_bwd_dx3(C.byref(d), C.byref(dyc), _ptr(dx3), _ptr(db3_part), _stream()),
-               'tamgcn_ctrgc_bwd_dx3')
     nct = Cout // 16
     dA_part = empty(N * nct, S, V, V, like=like)
     dw4_part = empty(N, S, Cout, R, like=like)
     db4_part = empty(N, S, Cout, like=like)
     dal_part = empty(N * nct, 1, like=like)
     dpq = torch.zeros(S * 2 * R, N, V, device=like.device, dtype=torch.float32)
-    _lib.check(lib.tamgcn_ctrgc_bwd_de(C.byref(d), C.byref(dyc), _ptr(dA_part), _ptr(dw4_part), _ptr(db4_part),
-                                       _ptr(dal_part), _ptr(dpq), _stream()), 'tamgcn_ctrgc_bwd_de')
-    return (dx3, reduce_sum(db3_part, N), reduce_sum(dA_part, N * nct), reduce_sum(dw4_part, N),
-            reduce_sum(db4_part, N), reduce_sum(dal_part, N * nct), dpq)
+    _lib.check(_lib_().tamgcn_ctrgc_bwd_de(C.byref(d), C.byref(dyc), _ptr(dA_part), _ptr(dw4_part), _ptr(db4_part),
+                                           _ptr(dal_part), _ptr(dpq), _stream()), 'tamgcn_ctrgc_bwd_de')
+    return (reduce_sum(dA_part, N * nct), reduce_sum(dw4_part, N), reduce_sum(db4_part, N),
+            reduce_sum(dal_part, N * nct), dpq)
+
+
+def ctrgc_bwd(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy):
+    """Returns dx3 (N,S*Cout,T,V), db3 [S*Cout], dA [S,V,V], dw4 [S,Cout,R], db4 [S,Cout], dalpha [1], dpq [S*2*R,N,V]."""
+    dx3, db3 = ctrgc_bwd_dx3(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy)
+    dA, dw4, db4, dal, dpq = ctrgc_bwd_de(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy)
+    return dx3, db3, dA, dw4, db4, dal, dpq
 
 
 # ---------------------------------------------------------------------------

@@ -35,6 +35,9 @@ CONV_CASES = [
     (1, 70, 40, 9, 25, 1, 1, 1),
     (1, 16, 16, 12, 20, 9, 1, 1),
     (1, 12, 12, 11, 20, 3, 3, 1),
+    (2, 64, 96, 40, 20, 1, 1, 1),      # two 48-row channel tiles, three frame tiles (staged epilogue overshoot)
+    (2, 192, 64, 33, 20, 1, 1, 1),     # K = 6 chunks, ragged last frame tile
+    (2, 48, 144, 16, 20, 1, 1, 1),
 ]
 
 
