@@ -170,14 +170,16 @@ typedef struct tamgcn_ctrgc_desc {
 
 /* y[n,c,t,u] = sum_s sum_v E_s[n,c,u,v] * (W3_s x + b3_s)[n,c,t,v],
  * E_s = alpha*(W4_s tanh(p_s[u]-q_s[v]) + b4_s) + A_s ; E lives only in LDS.
- * stats_part (optional): [2][Cout][N] partial (sum y, sum y^2) per sample. */
-int tamgcn_ctrgc_fwd(const tamgcn_ctrgc_desc* d, float* y, float* stats_part, void* stream);
+ * stats_part (optional): [2][Cout][N] partial (sum y, sum y^2) per sample.
+ * x3_out (optional): (N, S*Cout, T, V) receives x3 = W3 x + b3 (the tile is in LDS anyway) so that
+ * the backward need not recompute the GEMM; NULL keeps the forward write-minimal. */
+int tamgcn_ctrgc_fwd(const tamgcn_ctrgc_desc* d, float* y, float* stats_part, float* x3_out, void* stream);
 
 /* dx3[n, s*Cout+c, t, v] = sum_u E_s[n,c,u,v] * dy(n,c,t,u);  db3_part [N][S*Cout] */
 int tamgcn_ctrgc_bwd_dx3(const tamgcn_ctrgc_desc* d, const tamgcn_src* dy,
                          float* dx3, float* db3_part, void* stream);
 
-/* dE_s[n,c,u,v] = sum_t dy(n,c,t,u) * x3_s[n,c,t,v] (x3 recomputed, never stored) pushed
+/* dE_s[n,c,u,v] = sum_t dy(n,c,t,u) * x3_s[n,c,t,v] (x3 recomputed on chip, never stored) pushed
  * through E's definition:
  *   dA_part     [N*nct][S][V][V]   (sum over the block's channels)
  *   dw4_part    [N][S][Cout][R], db4_part [N][S][Cout], dalpha_part [N*nct]
@@ -186,6 +188,18 @@ int tamgcn_ctrgc_bwd_dx3(const tamgcn_ctrgc_desc* d, const tamgcn_src* dy,
 int tamgcn_ctrgc_bwd_de(const tamgcn_ctrgc_desc* d, const tamgcn_src* dy,
                         float* dA_part, float* dw4_part, float* db4_part, float* dalpha_part,
                         float* dpq, void* stream);
+
+/* The same chain when tamgcn_ctrgc_fwd kept x3 (x3_out), as two launches:
+ *   _de_acc   dE (N, S, Cout, V, V) = sum_t dy(n,c,t,u) * x3[n, s*Cout+c, t, v]     (streaming, HBM-bound)
+ *   _de_tail  one workgroup per (n, s): dA_part [N][S][V][V], dw4_part [N][S][Cout][R],
+ *             db4_part [N][S][Cout], dalpha_part [N*S], dpq [S*2*R][N][V] (plain stores: every
+ *             (n, s) owns its slice, nothing to zero).  R <= 32.
+ * d->x and d->w3/b3 are not read by either. */
+int tamgcn_ctrgc_bwd_de_acc(const tamgcn_ctrgc_desc* d, const tamgcn_src* dy, const float* x3,
+                            float* dE, void* stream);
+int tamgcn_ctrgc_bwd_de_tail(const tamgcn_ctrgc_desc* d, const float* dE,
+                             float* dA_part, float* dw4_part, float* db4_part,
+                             float* dalpha_part, float* dpq, void* stream);
 
 /* ------------------------------------------------------------------------
  * Element-wise block epilogues and their backward reductions.

@@ -87,3 +87,9 @@ __device__ __forceinline__ float wave_sum64(float v) {
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+
+// tanh(x) = 1 - 2/(exp(2x)+1): absolute error ~1e-7 (D is O(1) and enters E linearly)
+__device__ __forceinline__ float fast_tanh(float x) {
+    float e = __expf(2.f * x);
+    return 1.f - __fdividef(2.f, e + 1.f);
+}

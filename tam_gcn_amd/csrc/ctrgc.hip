@@ -64,11 +64,6 @@ __device__ __forceinline__ bool block_coords(const CtrgcArgs& a, int& n, int& c0
     return n < a.N;
 }
 
-// tanh(x) = 1 - 2/(exp(2x)+1): absolute error ~1e-7 (D is O(1) and enters E linearly)
-__device__ __forceinline__ float fast_tanh(float x) {
-    float e = __expf(2.f * x);
-    return 1.f - __fdividef(2.f, e + 1.f);
-}
 
 
 // D[r][u*V+v] = tanh(p[r][u] - q[r][v]) for rel-channels r0..r0+rc-1 of subset s, sample n.
@@ -357,7 +352,7 @@ struct DyTile {
 // forward
 // ---------------------------------------------------------------------------
 template <class G, int ST>
-__global__ __launch_bounds__(G::NT) void ctrgc_fwd_kernel(const CtrgcArgs a, float* y, float* stats_part) {
+__global__ __launch_bounds__(G::NT) void ctrgc_fwd_kernel(const CtrgcArgs a, float* y, float* stats_part, float* x3_out) {
     constexpr int V = G::V, TB = G::TB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int n, c0;
@@ -404,6 +399,19 @@ __global__ __launch_bounds__(G::NT) void ctrgc_fwd_kernel(const CtrgcArgs a, flo
             yrow[p] = v;
             st1 += v;
             st2 = fmaf(v, v, st2);
+        }
+        if (x3_out) {             // keep x3 for the backward (saves recomputing the GEMM there)
+#pragma unroll
+            for (int s = 0; s < ST; ++s) {
+                float* xo = x3_out + (((long long)n * ST * a.Cout + s * a.Cout + c0 + c) * a.T + t0) * V;
+                const float* xi = X3 + (s * 16 + c) * G::PX3;
+                if constexpr (G::VEC) {
+                    for (int p4 = lrow; p4 < (ncols >> 2); p4 += G::NTQ * 4)
+                        reinterpret_cast<float4*>(xo)[p4] = reinterpret_cast<const float4*>(xi)[p4];
+                } else {
+                    for (int p = lrow; p < ncols; p += G::NTQ * 4) xo[p] = xi[p];
+                }
+            }
         }
         // next chunk's first barrier (inside x3_chunk) protects Zs / X3 reuse
     }
@@ -749,13 +757,13 @@ extern "C" int tamgcn_ctrgc_lds_bytes(int S, int V, int R) {
     return (int)p.lds;
 }
 
-extern "C" int tamgcn_ctrgc_fwd(const tamgcn_ctrgc_desc* d, float* y, float* stats_part, void* stream) {
+extern "C" int tamgcn_ctrgc_fwd(const tamgcn_ctrgc_desc* d, float* y, float* stats_part, float* x3_out, void* stream) {
     TG_CHECK(d && y, "tamgcn_ctrgc_fwd: null pointer");
     CtrgcPlan p;
     TG_CHECK(plan_ctrgc(d->S, d->V, &p) == 0, "tamgcn_ctrgc_fwd: unsupported S=%d V=%d (LDS-resident tiles exist for S in {1,3}, V in {20,25})", d->S, d->V);
     CtrgcArgs a;
     if (fill_args(d, p, &a, "tamgcn_ctrgc_fwd")) return -1;
-    CTRGC_DISPATCH(ctrgc_fwd_kernel, a, y, stats_part);
+    CTRGC_DISPATCH(ctrgc_fwd_kernel, a, y, stats_part, x3_out);
     TG_LAUNCH_CHECK("tamgcn_ctrgc_fwd");
     return 0;
 }

@@ -1,0 +1,462 @@
+// The dE chain of CTRGC's backward when the forward kept x3 (reference: autograd of
+// models/ctrgcn.py:172-177 and :252-254), as two kernels instead of one LDS-bound monolith:
+//
+//   ctrgc_de_acc_kernel   dE[n,s,c,u,v] = sum_t dy(n,c,t,u) * x3[n,s*Cout+c,t,v]
+//                         streaming, HBM-bound: reads 4 activations' worth, writes N*S*Cout*V*V
+//   ctrgc_de_tail_kernel  one workgroup per (n, s) pushes dE through E = alpha*(W4 D + b4) + A,
+//                         D = tanh(p_u - q_v): dA, db4, dW4 (MFMA, K = V*V), dD = W4^T dE (MFMA,
+//                         K = Cout), dp / dq row / column sums.  Every (n, s) owns its slice of
+//                         dpq, so there are no atomics and nothing to zero.
+//
+// Splitting costs one round trip of dE through HBM (<= 315 MB per layer at batch 256) and removes a
+// per-channel-tile tail that was latency-bound with a single 159 KB workgroup per CU.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// kernel A: accumulate dE
+// ---------------------------------------------------------------------------------------------
+template <int V_, int ST_>
+struct AccGeo {
+    static constexpr int V = V_, ST = ST_, VV = V * V;
+    static constexpr int CA = 8;                       // channels per workgroup
+    static constexpr int NT = 256;
+    static constexpr bool VEC = (V % 4 == 0);
+    static constexpr int BT = V <= 20 ? 16 : 8;        // frames per chunk
+    static constexpr int NCOLS = BT * V;
+    // x3 rows: three consecutive rows meet in one ds_read_b128 lane group -> offset rows by one 16-B slot
+    static constexpr int PX = NCOLS + 4;
+    // dy rows: owners read 2 joints (8 B) each, 10 owners per row: pitch = 20 banks (mod 64) packs the
+    // rows of a 32-lane group into 64 distinct banks
+    static constexpr int PZ = NCOLS + 20;
+    static constexpr int NUG0 = (NT / (ST * CA)) < V ? (NT / (ST * CA)) : V;
+    static constexpr int UBG = (V + NUG0 - 1) / NUG0;  // joints per owner
+    static constexpr int NUG = (V + UBG - 1) / UBG;
+    static constexpr int NOWN = ST * CA * NUG;
+    static constexpr int VECW = VEC ? 4 : 1;
+    static constexpr int ROWV = NCOLS / VECW;
+    static constexpr int NX = (ST * CA * ROWV + NT - 1) / NT;
+    static constexpr int NY = (CA * ROWV + NT - 1) / NT;
+    static constexpr size_t LDS = sizeof(float) * (size_t)(ST * CA * PX + CA * PZ);
+    static_assert(NOWN <= NT, "not enough threads for the dE owners");
+};
+
+template <class G>
+__global__ __launch_bounds__(G::NT) void ctrgc_de_acc_kernel(int N, int Cout, int T, const float* __restrict__ x3, const SrcDev dy,
+                                                             float* __restrict__ dE) {
+    constexpr int V = G::V, VV = G::VV, ST = G::ST, NT = G::NT, CA = G::CA, UBG = G::UBG, VECW = G::VECW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X3 = smem;                    // [ST*CA][PX]
+    float* Zs = smem + ST * CA * G::PX;  // [CA][PZ]
+    const int nca = Cout / CA;
+    const int n = blockIdx.x / nca, c0 = (blockIdx.x - n * nca) * CA;
+    const int tid = threadIdx.x;
+    const int own_s = tid / (CA * G::NUG), own_c = (tid / G::NUG) % CA, own_g = tid % G::NUG;
+    const bool owner = tid < G::NOWN;
+    const long long cs = (long long)T * V;
+
+    float xq[G::NX][VECW], y1[G::NY][VECW], y2[G::NY][VECW], k1[G::NY], k2[G::NY], k0[G::NY];
+    auto load = [&](int t0, int bt) {
+        const int ncols = bt * V;
+#pragma unroll
+        for (int i = 0; i < G::NX; ++i) {
+            int e = tid + i * NT;
+            int row = e / G::ROWV, pos = (e - row * G::ROWV) * VECW;
+            bool ok = row < ST * CA && pos < ncols;
+            int s = row / CA, c = row - s * CA;
+            long long g = (((long long)n * ST + s) * Cout + c0 + c) * cs + (long long)t0 * V + pos;
+            if constexpr (G::VEC) {
+                float4 t = ok ? *reinterpret_cast<const float4*>(x3 + g) : make_float4(0.f, 0.f, 0.f, 0.f);
+                xq[i][0] = t.x; xq[i][1] = t.y; xq[i][2] = t.z; xq[i][3] = t.w;
+            } else {
+                xq[i][0] = ok ? x3[g] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < G::NY; ++i) {
+            int e = tid + i * NT;
+            int row = e / G::ROWV, pos = (e - row * G::ROWV) * VECW;
+            bool ok = row < CA && pos < ncols;
+            int ch = dy.coff + c0 + (ok ? row : 0);
+            long long g = ((long long)n * dy.ctot + ch) * cs + (long long)t0 * V + (ok ? pos : 0);
+            k1[i] = dy.coef ? dy.coef[ch] : 1.f;
+            k2[i] = (dy.coef && dy.x2) ? dy.coef[dy.ctot + ch] : 0.f;
+            k0[i] = dy.coef ? dy.coef[2 * dy.ctot + ch] : 0.f;
+            if constexpr (G::VEC) {
+                float4 t = ok ? *reinterpret_cast<const float4*>(dy.x1 + g) : make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 u = (ok && dy.x2) ? *reinterpret_cast<const float4*>(dy.x2 + g) : make_float4(0.f, 0.f, 0.f, 0.f);
+                y1[i][0] = t.x; y1[i][1] = t.y; y1[i][2] = t.z; y1[i][3] = t.w;
+                y2[i][0] = u.x; y2[i][1] = u.y; y2[i][2] = u.z; y2[i][3] = u.w;
+            } else {
+                y1[i][0] = ok ? dy.x1[g] : 0.f;
+                y2[i][0] = (ok && dy.x2) ? dy.x2[g] : 0.f;
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < G::NX; ++i) {
+            int e = tid + i * NT;
+            int row = e / G::ROWV, pos = (e - row * G::ROWV) * VECW;
+            if (row < ST * CA) {
+                if constexpr (G::VEC) *reinterpret_cast<float4*>(X3 + row * G::PX + pos) = make_float4(xq[i][0], xq[i][1], xq[i][2], xq[i][3]);
+                else X3[row * G::PX + pos] = xq[i][0];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < G::NY; ++i) {
+            int e = tid + i * NT;
+            int row = e / G::ROWV, pos = (e - row * G::ROWV) * VECW;
+            if (row < CA) {
+                float o[VECW];
+#pragma unroll
+                for (int k = 0; k < VECW; ++k) {
+                    float v = fmaf(k1[i], y1[i][k], fmaf(k2[i], y2[i][k], k0[i]));
+                    o[k] = dy.act == 1 ? fmaxf(v, 0.f) : v;
+                }
+                if constexpr (G::VEC) *reinterpret_cast<float4*>(Zs + row * G::PZ + pos) = make_float4(o[0], o[1], o[2], o[3]);
+                else Zs[row * G::PZ + pos] = o[0];
+            }
+        }
+    };
+
+    float acc[UBG][V];
+#pragma unroll
+    for (int i = 0; i < UBG; ++i)
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[i][v] = 0.f;
+
+    // No register prefetch across the FMAs: three workgroups share a CU (42 KB of LDS, <= 168 VGPRs each)
+    // and cover each other's load phases; holding the next chunk in registers would cost the third one.
+    for (int t0 = 0; t0 < T; t0 += G::BT) {
+        const int bt = min(G::BT, T - t0);
+        load(t0, bt);
+        __syncthreads();                               // owners are done with the previous chunk
+        commit();
+        __syncthreads();
+        if (owner) {
+            const float* xr = X3 + (own_s * CA + own_c) * G::PX;
+            const float* dr = Zs + own_c * G::PZ + own_g * UBG;
+            for (int tl = 0; tl < bt; ++tl) {
+                float xv[V], d[UBG];
+                if constexpr (G::VEC) {
+#pragma unroll
+                    for (int v = 0; v < V; v += 4) {
+                        f32x4 t = *reinterpret_cast<const f32x4*>(xr + tl * V + v);
+                        xv[v] = t[0]; xv[v + 1] = t[1]; xv[v + 2] = t[2]; xv[v + 3] = t[3];
+                    }
+                } else {
+#pragma unroll
+                    for (int v = 0; v < V; ++v) xv[v] = xr[tl * V + v];
+                }
+                if constexpr (UBG == 2 && V % 2 == 0) {
+                    float2 t = *reinterpret_cast<const float2*>(dr + tl * V);
+                    d[0] = t.x; d[1] = t.y;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < UBG; ++i) d[i] = (own_g * UBG + i < V) ? dr[tl * V + i] : 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < UBG; ++i)
+#pragma unroll
+                    for (int v = 0; v < V; ++v) acc[i][v] = fmaf(d[i], xv[v], acc[i][v]);
+            }
+        }
+    }
+    if (owner) {
+        float* o = dE + (((long long)n * ST + own_s) * Cout + c0 + own_c) * VV;
+#pragma unroll
+        for (int i = 0; i < UBG; ++i) {
+            const int u = own_g * UBG + i;
+            if (u < V) {
+                if constexpr (G::VEC) {
+#pragma unroll
+                    for (int v = 0; v < V; v += 4)
+                        *reinterpret_cast<float4*>(o + u * V + v) = make_float4(acc[i][v], acc[i][v + 1], acc[i][v + 2], acc[i][v + 3]);
+                } else {
+#pragma unroll
+                    for (int v = 0; v < V; ++v) o[u * V + v] = acc[i][v];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel B: dE -> dA, db4, dW4, dalpha, dp, dq     (one workgroup per (n, s))
+// ---------------------------------------------------------------------------------------------
+struct TailArgs {
+    int N, Cout, S, R;
+    const float* dE; const float* pq; const float* w4; const float* b4; const float* alpha;
+    float* dA_part; float* dw4_part; float* db4_part; float* dalpha_part; float* dpq;
+};
+
+constexpr int tail_pitch(int vv) {   // smallest pitch >= vv with pitch % 16 == 2: 16 rows x 2 k hit 32 banks
+    int p = vv;
+    while (p % 16 != 2) ++p;
+    return p;
+}
+
+template <int V, int RT>
+__global__ __launch_bounds__(256) void ctrgc_de_tail_kernel(const TailArgs a) {
+    constexpr int VV = V * V, PD = tail_pitch(VV), NT = 256, NW = 4;
+    constexpr int NCT = (VV + 15) / 16, TPW = (NCT + NW - 1) / NW;
+    constexpr int NA = (VV + NT - 1) / NT;
+    constexpr int NCH = (16 * VV / 4 + NT - 1) / NT;
+    constexpr int KST = (VV + 3) / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float red_alpha[NW];
+    float* Ds = smem;                        // [R][PD]    D, later dS in place
+    float* DEs = Ds + a.R * PD;              // [16][PD]   dE chunk
+    float* red = DEs + 16 * PD;              // [NW][16][RT*16]
+    const int n = blockIdx.x / a.S, s = blockIdx.x - n * a.S;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, mj = lane & 15, mkq = lane >> 4;
+    const long long NV = (long long)a.N * V;
+    const float alpha = a.alpha[0];
+
+    float4 pre[NCH];
+    auto load = [&](int c0) {
+        const float4* g = reinterpret_cast<const float4*>(a.dE + (((long long)n * a.S + s) * a.Cout + c0) * VV);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            int e = tid + i * NT;
+            pre[i] = e < 16 * VV / 4 ? g[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    load(0);
+    {   // D[r][uv] = tanh(p[r][u] - q[r][v]); four (p, q) pairs in flight per thread
+        const float* pb = a.pq + ((long long)(s * 2 + 0) * a.R) * NV + (long long)n * V;
+        const float* qb = a.pq + ((long long)(s * 2 + 1) * a.R) * NV + (long long)n * V;
+        const int total = a.R * VV;
+        for (int e0 = tid; e0 < total; e0 += 4 * NT) {
+            float pv[4], qv[4];
+            int off[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int e = e0 + i * NT;
+                int ec = e < total ? e : 0;
+                int r = ec / VV, uv = ec - r * VV;
+                int u = uv / V, v = uv - u * V;
+                pv[i] = pb[r * NV + u];
+                qv[i] = qb[r * NV + v];
+                off[i] = e < total ? r * PD + uv : -1;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (off[i] >= 0) Ds[off[i]] = fast_tanh(pv[i] - qv[i]);
+        }
+    }
+    f32x4 accG[TPW][RT];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) accG[j][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float accA[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) accA[i] = 0.f;
+    float dalpha_acc = 0.f;
+
+    for (int c0 = 0; c0 < a.Cout; c0 += 16) {
+        // W4^T fragment of this chunk: A[i = r][k = c]
+        float aw[RT][4];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4)
+                aw[rt][k4] = (rt * 16 + mj < a.R) ? a.w4[((long long)s * a.Cout + c0 + k4 * 4 + mkq) * a.R + rt * 16 + mj] : 0.f;
+        __syncthreads();                     // previous chunk (and the D fill) done
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            int e4 = (tid + i * NT) * 4;
+            if (e4 < 16 * VV) {
+                float vals[4] = {pre[i].x, pre[i].y, pre[i].z, pre[i].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    int e = e4 + k;
+                    int c = e / VV, uv = e - c * VV;
+                    DEs[c * PD + uv] = vals[k];
+                }
+            }
+        }
+        __syncthreads();
+        if (c0 + 16 < a.Cout) load(c0 + 16);
+        // dG[r][uv] += sum_c W4[c][r] dE[c][uv]
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+            const int ct = wave + j * NW;
+            if (ct < NCT) {
+                const int col = ct * 16 + mj;
+                const int colc = col < VV ? col : VV - 1;
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    float b = DEs[(k4 * 4 + mkq) * PD + colc];
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) accG[j][rt] = mfma16(aw[rt][k4], b, accG[j][rt]);
+                }
+            }
+        }
+        // dA partial: sum over channels
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            int uv = tid + i * NT;
+            if (uv < VV) {
+                float t = 0.f;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) t += DEs[c * PD + uv];
+                accA[i] += t;
+            }
+        }
+        // db4raw[c] = sum_uv dE[c][uv]
+        {
+            const int c = tid >> 4, l16 = tid & 15;
+            float t = 0.f;
+            for (int uv = l16; uv < VV; uv += 16) t += DEs[c * PD + uv];
+            t = wave_sum16(t);
+            if (l16 == 0) {
+                a.db4_part[((long long)n * a.S + s) * a.Cout + c0 + c] = alpha * t;
+                dalpha_acc = fmaf(a.b4[s * a.Cout + c0 + c], t, dalpha_acc);
+            }
+        }
+        // dW4raw[c][r] = sum_uv dE[c][uv] D[r][uv]: K = VV split over the four waves
+        {
+            f32x4 accW[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) accW[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int st = wave; st < KST; st += NW) {
+                const int k = st * 4 + mkq;
+                const bool kok = k < VV;
+                float av = kok ? DEs[mj * PD + k] : 0.f;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const int r = rt * 16 + mj;
+                    float bv = (kok && r < a.R) ? Ds[r * PD + k] : 0.f;
+                    accW[rt] = mfma16(av, bv, accW[rt]);
+                }
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) red[(wave * 16 + mkq * 4 + rr) * (RT * 16) + rt * 16 + mj] = accW[rt][rr];
+        }
+        __syncthreads();
+        for (int e = tid; e < 16 * RT * 16; e += NT) {
+            const int c = e / (RT * 16), r = e - c * (RT * 16);
+            if (r < a.R) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) t += red[(w * 16 + c) * (RT * 16) + r];
+                const long long wi = ((long long)s * a.Cout + c0 + c) * a.R + r;
+                a.dw4_part[(long long)n * a.S * a.Cout * a.R + wi] = alpha * t;
+                dalpha_acc = fmaf(a.w4[wi], t, dalpha_acc);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        int uv = tid + i * NT;
+        if (uv < VV) a.dA_part[((long long)n * a.S + s) * VV + uv] = accA[i];
+    }
+    __syncthreads();                         // every wave is done reading D
+    // dS[r][uv] = alpha * dG * (1 - D^2), in place over D
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int ct = wave + j * NW;
+        const int col = ct * 16 + mj;
+        if (ct < NCT && col < VV) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int r = rt * 16 + mkq * 4 + rr;
+                    if (r < a.R) {
+                        float d = Ds[r * PD + col];
+                        Ds[r * PD + col] = alpha * accG[j][rt][rr] * (1.f - d * d);
+                    }
+                }
+        }
+    }
+    __syncthreads();
+    // dp[r][u] = sum_v dS[r][u][v];  dq[r][v] = -sum_u dS[r][u][v]
+    for (int e = tid; e < a.R * V * 2; e += NT) {
+        const int which = e / (a.R * V);
+        const int rem = e - which * a.R * V;
+        const int r = rem / V, k = rem - r * V;
+        float t = 0.f;
+        if (which == 0) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) t += Ds[r * PD + k * V + v];
+        } else {
+#pragma unroll
+            for (int u = 0; u < V; ++u) t -= Ds[r * PD + u * V + k];
+        }
+        a.dpq[((long long)(s * 2 + which) * a.R + r) * NV + (long long)n * V + k] = t;
+    }
+    dalpha_acc = wave_sum64(dalpha_acc);
+    if (lane == 0) red_alpha[wave] = dalpha_acc;
+    __syncthreads();
+    if (tid == 0) a.dalpha_part[n * a.S + s] = red_alpha[0] + red_alpha[1] + red_alpha[2] + red_alpha[3];
+}
+
+template <typename K>
+void allow_lds(K kernel, size_t lds, bool* done) {
+    if (!*done && lds > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        *done = true;
+    }
+}
+
+template <int V>
+size_t tail_lds(int R, int RT) { return sizeof(float) * ((size_t)(R + 16) * tail_pitch(V * V) + 4 * 16 * RT * 16); }
+
+}  // namespace
+
+#define DE_ACC_CASE(VV_, SS_)                                                                                          \
+    if (d->V == VV_ && d->S == SS_) {                                                                                  \
+        using G = AccGeo<VV_, SS_>;                                                                                    \
+        static bool flag = false;                                                                                      \
+        allow_lds(ctrgc_de_acc_kernel<G>, G::LDS, &flag);                                                              \
+        hipLaunchKernelGGL((ctrgc_de_acc_kernel<G>), dim3(d->N * (d->Cout / G::CA)), dim3(G::NT), G::LDS, (hipStream_t)stream, \
+                           d->N, d->Cout, d->T, x3, make_src(*dy), dE);                                                \
+        tamgcn_note_kernel("ctrgc_de_acc_kernel<AccGeo<%d, %d>>", VV_, SS_);                                           \
+        launched = true;                                                                                               \
+    }
+
+extern "C" int tamgcn_ctrgc_bwd_de_acc(const tamgcn_ctrgc_desc* d, const tamgcn_src* dy, const float* x3, float* dE, void* stream) {
+    TG_CHECK(d && dy && dy->x1 && x3 && dE, "tamgcn_ctrgc_bwd_de_acc: null pointer");
+    TG_CHECK(d->N > 0 && d->T > 0 && d->Cout > 0 && d->Cout % 16 == 0, "tamgcn_ctrgc_bwd_de_acc: bad shape N=%d T=%d Cout=%d", d->N, d->T, d->Cout);
+    TG_CHECK(dy->ctot >= dy->coff + d->Cout, "tamgcn_ctrgc_bwd_de_acc: dy has %d channels from %d, need %d", dy->ctot, dy->coff, d->Cout);
+    bool launched = false;
+    DE_ACC_CASE(20, 3) else DE_ACC_CASE(20, 1) else DE_ACC_CASE(25, 3) else DE_ACC_CASE(25, 1)
+    TG_CHECK(launched, "tamgcn_ctrgc_bwd_de_acc: unsupported S=%d V=%d (S in {1,3}, V in {20,25})", d->S, d->V);
+    TG_LAUNCH_CHECK("tamgcn_ctrgc_bwd_de_acc");
+    return 0;
+}
+
+#define DE_TAIL_CASE(VV_, RT_)                                                                                         \
+    if (d->V == VV_ && rt == RT_) {                                                                                    \
+        static bool flag = false;                                                                                      \
+        const size_t lds = tail_lds<VV_>(d->R, RT_);                                                                   \
+        allow_lds(ctrgc_de_tail_kernel<VV_, RT_>, tail_lds<VV_>(32, 2), &flag);                                        \
+        hipLaunchKernelGGL((ctrgc_de_tail_kernel<VV_, RT_>), dim3(d->N * d->S), dim3(256), lds, (hipStream_t)stream, a); \
+        tamgcn_note_kernel("ctrgc_de_tail_kernel<%d, %d>", VV_, RT_);                                                  \
+        launched = true;                                                                                               \
+    }
+
+extern "C" int tamgcn_ctrgc_bwd_de_tail(const tamgcn_ctrgc_desc* d, const float* dE, float* dA_part, float* dw4_part, float* db4_part,
+                                        float* dalpha_part, float* dpq, void* stream) {
+    TG_CHECK(d && dE && dA_part && dw4_part && db4_part && dalpha_part && dpq, "tamgcn_ctrgc_bwd_de_tail: null pointer");
+    TG_CHECK(d->pq && d->w4 && d->b4 && d->alpha, "tamgcn_ctrgc_bwd_de_tail: null parameter pointer");
+    TG_CHECK(d->N > 0 && d->S > 0 && d->Cout > 0 && d->Cout % 16 == 0, "tamgcn_ctrgc_bwd_de_tail: bad shape N=%d S=%d Cout=%d", d->N, d->S, d->Cout);
+    TG_CHECK(d->R >= 1 && d->R <= 32, "tamgcn_ctrgc_bwd_de_tail: R=%d outside 1..32 (use tamgcn_ctrgc_bwd_de)", d->R);
+    TailArgs a;
+    a.N = d->N; a.Cout = d->Cout; a.S = d->S; a.R = d->R;
+    a.dE = dE; a.pq = d->pq; a.w4 = d->w4; a.b4 = d->b4; a.alpha = d->alpha;
+    a.dA_part = dA_part; a.dw4_part = dw4_part; a.db4_part = db4_part; a.dalpha_part = dalpha_part; a.dpq = dpq;
+    const int rt = d->R <= 16 ? 1 : 2;
+    bool launched = false;
+    DE_TAIL_CASE(20, 1) else DE_TAIL_CASE(20, 2) else DE_TAIL_CASE(25, 1) else DE_TAIL_CASE(25, 2)
+    TG_CHECK(launched, "tamgcn_ctrgc_bwd_de_tail: unsupported V=%d (V in {20,25})", d->V);
+    TG_LAUNCH_CHECK("tamgcn_ctrgc_bwd_de_tail");
+    return 0;
+}

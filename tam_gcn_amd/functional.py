@@ -26,6 +26,9 @@ from .ops import S, RELU
 # ---------------------------------------------------------------------------
 _SIDE = {}
 USE_SIDE_STREAMS = os.environ.get('TAMGCN_SIDE_STREAMS', '1') != '0'
+# keep x3 = conv3(x) from the forward for the backward (3 x one activation per block, ~3 GB at batch 256)
+# instead of recomputing the GEMM there; TAMGCN_KEEP_X3=0 trades the memory back for time
+KEEP_X3 = os.environ.get('TAMGCN_KEEP_X3', '1') != '0'
 
 
 class Fork:
@@ -121,7 +124,8 @@ def gcn_forward(x, P, training, save):
     xbar = ops.tmean(xs, Cin)                                             # (Cin, N, V)
     pq, _ = ops.conv(S(xbar.view(1, Cin, N, V)), K=Cin, w=P.W12, bias=P.B12, M=S_ * 2 * R)
     pq = pq.view(S_ * 2 * R, N, V)
-    y_pre, ypart = ops.ctrgc_fwd(xs, pq, P.W3, P.B3, P.W4, P.B4, P.PA, P.alpha, Cin, Cout, S_, R, stats=training)
+    y_pre, ypart, x3 = ops.ctrgc_fwd(xs, pq, P.W3, P.B3, P.W4, P.B4, P.PA, P.alpha, Cin, Cout, S_, R, stats=training,
+                                     keep_x3=save and KEEP_X3)
     coef_y, save_y = _coef(Cout, x)
     P.bn.fwd(ypart, 0, count, training, coef_y, save_y, 0)
     fk.__exit__()                                      # join: d_pre and its coefficients are needed now
@@ -143,7 +147,7 @@ def gcn_forward(x, P, training, save):
     g = ops.gcn_tail_fwd(S(y_pre, coef=coef_y), S(o_pre, coef=coef_o), res)
     sv = None
     if save:
-        sv = dict(x=x, xbar=xbar, pq=pq, y_pre=y_pre, d_pre=d_pre, o_pre=o_pre, g=g, coef_y=coef_y, save_y=save_y,
+        sv = dict(x=x, xbar=xbar, pq=pq, x3=x3, y_pre=y_pre, d_pre=d_pre, o_pre=o_pre, g=g, coef_y=coef_y, save_y=save_y,
                   coef_d=coef_d, save_d=save_d, coef_o=coef_o, save_o=save_o, coef_diff=coef_diff,
                   training=training)
     return g, sv
@@ -183,7 +187,7 @@ def gcn_backward(P, sv, dg, need_dx=True, extra_dx=None):
     cargs = (xs, pq, P.W3, P.B3, P.W4, P.B4, P.PA, P.alpha, Cin, Cout, S_, R, dy)
     fk.refork()                                        # dyb / coefb_y are ready on main
     with fk.on(1):                                     # the dE chain runs beside the dx3 -> dx chain
-        G['PA'], G['W4'], G['B4'], G['alpha'], dpq = ops.ctrgc_bwd_de(*cargs)
+        G['PA'], G['W4'], G['B4'], G['alpha'], dpq = ops.ctrgc_bwd_de(*cargs, x3=sv['x3'])
         dpq4 = S(dpq.view(1, S_ * 2 * R, N, V))
         G['W12'] = ops.wgrad(dpq4, S(xbar.view(1, Cin, N, V)), M=S_ * 2 * R, K=Cin)
         G['B12'] = dpq.sum((1, 2))
@@ -460,7 +464,7 @@ class CTRGCFn(torch.autograd.Function):
         xbar = ops.tmean(xs, Cin)
         pq, _ = ops.conv(S(xbar.view(1, Cin, N, V)), K=Cin, w=W12, bias=B12, M=2 * R)
         pq = pq.view(2 * R, N, V)
-        y, _ = ops.ctrgc_fwd(xs, pq, W3, b3, W4, b4.reshape(1, Cout), A3, al, Cin, Cout, 1, R, stats=False)
+        y, _, _ = ops.ctrgc_fwd(xs, pq, W3, b3, W4, b4.reshape(1, Cout), A3, al, Cin, Cout, 1, R, stats=False)
         ctx.sv = (x, xbar, pq, W12, W3, b3, W4, b4.reshape(1, Cout), A3, al)
         ctx.shapes = (A.shape, alpha.shape, w1.shape, w3.shape, w4.shape)
         return y

@@ -167,13 +167,15 @@ def _ctrgc_desc(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R):
     return d
 
 
-def ctrgc_fwd(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, stats):
+def ctrgc_fwd(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, stats, keep_x3=False):
+    """Returns (y, stats_part, x3); x3 (N,S*Cout,T,V) only when keep_x3 (for the backward)."""
     N, _, T, V = x.x1.shape
     d = _ctrgc_desc(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R)
     y = empty(N, Cout, T, V, like=x.x1)
     part = empty(2, Cout, N, like=x.x1) if stats else None
-    _lib.check(_lib_().tamgcn_ctrgc_fwd(C.byref(d), _ptr(y), _ptr(part), _stream()), 'tamgcn_ctrgc_fwd')
-    return y, part
+    x3 = empty(N, S * Cout, T, V, like=x.x1) if keep_x3 else None
+    _lib.check(_lib_().tamgcn_ctrgc_fwd(C.byref(d), _ptr(y), _ptr(part), _ptr(x3), _stream()), 'tamgcn_ctrgc_fwd')
+    return y, part, x3
 
 
 def ctrgc_bwd_dx3(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy):
@@ -188,12 +190,28 @@ def ctrgc_bwd_dx3(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy):
     return dx3, reduce_sum(db3_part, N)
 
 
-def ctrgc_bwd_de(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy):
-    """The dE chain: dA [S,V,V], dw4 [S,Cout,R], db4 [S,Cout], dalpha [1], dpq [S*2*R,N,V]."""
+def ctrgc_bwd_de(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy, x3=None):
+    """The dE chain: dA [S,V,V], dw4 [S,Cout,R], db4 [S,Cout], dalpha [1], dpq [S*2*R,N,V].
+
+    With x3 (kept by ctrgc_fwd) and R <= 32: a streaming accumulation of dE plus one per-(n, s)
+    tail launch; otherwise the fused kernel that recomputes x3 on chip."""
     N, _, T, V = x.x1.shape
     d = _ctrgc_desc(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R)
     dyc = dy.c()
     like = x.x1
+    if x3 is not None and R <= 32:
+        dE = empty(N, S, Cout, V, V, like=like)
+        _lib.check(_lib_().tamgcn_ctrgc_bwd_de_acc(C.byref(d), C.byref(dyc), _ptr(x3), _ptr(dE), _stream()),
+                   'tamgcn_ctrgc_bwd_de_acc')
+        dA_part = empty(N, S, V, V, like=like)
+        dw4_part = empty(N, S, Cout, R, like=like)
+        db4_part = empty(N, S, Cout, like=like)
+        dal_part = empty(N * S, 1, like=like)
+        dpq = empty(S * 2 * R, N, V, like=like)
+        _lib.check(_lib_().tamgcn_ctrgc_bwd_de_tail(C.byref(d), _ptr(dE), _ptr(dA_part), _ptr(dw4_part), _ptr(db4_part),
+                                                    _ptr(dal_part), _ptr(dpq), _stream()), 'tamgcn_ctrgc_bwd_de_tail')
+        return (reduce_sum(dA_part, N), reduce_sum(dw4_part, N), reduce_sum(db4_part, N),
+                reduce_sum(dal_part, N * S), dpq)
     nct = Cout // 16
     dA_part = empty(N * nct, S, V, V, like=like)
     dw4_part = empty(N, S, Cout, R, like=like)
@@ -206,10 +224,10 @@ def ctrgc_bwd_de(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy):
             reduce_sum(dal_part, N * nct), dpq)
 
 
-def ctrgc_bwd(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy):
+def ctrgc_bwd(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy, x3=None):
     """Returns dx3 (N,S*Cout,T,V), db3 [S*Cout], dA [S,V,V], dw4 [S,Cout,R], db4 [S,Cout], dalpha [1], dpq [S*2*R,N,V]."""
     dx3, db3 = ctrgc_bwd_dx3(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy)
-    dA, dw4, db4, dal, dpq = ctrgc_bwd_de(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy)
+    dA, dw4, db4, dal, dpq = ctrgc_bwd_de(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy, x3)
     return dx3, db3, dA, dw4, db4, dal, dpq
 
 

@@ -169,14 +169,23 @@ def test_ctrgc_fused_fwd_bwd(shape):
     pq, _ = ops.conv(S(xb.view(1, Cin, N, V)), K=Cin, w=t(W12), bias=t(B12), M=S_ * 2 * R)
     pq = pq.view(S_ * 2 * R, N, V)
     close(pq, pqr, 1e-4, 1e-5, 'pq')
-    yg, part = ops.ctrgc_fwd(xs, pq, t(W3), t(B3), t(W4), t(B4), t(A), t(alpha), Cin, Cout, S_, R, stats=True)
+    yg, part, x3k = ops.ctrgc_fwd(xs, pq, t(W3), t(B3), t(W4), t(B4), t(A), t(alpha), Cin, Cout, S_, R, stats=True,
+                                  keep_x3=True)
     close(yg, y, 2e-4, 2e-4, 'ctrgc fwd')
+    x3r = torch.einsum('oc,nctv->notv', W3, x) + B3[None, :, None, None]
+    close(x3k, x3r, 2e-4, 2e-4, 'x3 kept for the backward')
+    yg0, _, none = ops.ctrgc_fwd(xs, pq, t(W3), t(B3), t(W4), t(B4), t(A), t(alpha), Cin, Cout, S_, R, stats=False)
+    assert none is None and torch.equal(yg0, yg)
     close(part[0].sum(-1), y.sum((0, 2, 3)), 1e-3, 1e-2, 'stats')
     close(part[1].sum(-1), (y * y).sum((0, 2, 3)), 1e-3, 1e-2, 'stats2')
     dx3, db3, dA, dW4, db4, dal, dpq = ops.ctrgc_bwd(xs, pq, t(W3), t(B3), t(W4), t(B4), t(A), t(alpha),
                                                      Cin, Cout, S_, R, S(t(cot)))
     gpq, = torch.autograd.grad((y * cot).sum(), pqr, retain_graph=True)
     sc = lambda g: 2e-4 * (float(g.abs().max()) + 1e-3)
+    # stored-x3 variant of the dE kernel against the recomputing one
+    for got, ref, nm in zip(ops.ctrgc_bwd_de(xs, pq, t(W3), t(B3), t(W4), t(B4), t(A), t(alpha), Cin, Cout, S_, R,
+                                             S(t(cot)), x3=x3k), (dA, dW4, db4, dal, dpq), ('dA', 'dW4', 'db4', 'dalpha', 'dpq')):
+        close(got, ref.cpu(), 1e-4, 0.25 * sc(ref.cpu()), nm + ' (stored x3)')
     close(dA, A.grad, 1e-3, sc(A.grad), 'dA')
     close(dW4, W4.grad, 1e-3, sc(W4.grad), 'dW4')
     close(db4, B4.grad, 1e-3, sc(B4.grad), 'db4')

@@ -78,9 +78,17 @@ if not only or 'ctrgc' in only:
         us = timeit(lambda: ops.ctrgc_fwd(S(x), pq, W3, B3, W4, B4, A, al, Cin, Cout, S_, R, stats=True))
         fl = N * S_ * (2.0 * Cin * Cout * T * V + 2.0 * R * Cout * V * V + 2.0 * Cout * T * V * V)
         rep('ctrgc_fwd ' + nm, us, 4.0 * N * T * V * (Cin + Cout), fl)
+        us = timeit(lambda: ops.ctrgc_fwd(S(x), pq, W3, B3, W4, B4, A, al, Cin, Cout, S_, R, stats=True, keep_x3=True))
+        rep('ctrgc_fwd +x3 store ' + nm, us, 4.0 * N * T * V * (Cin + 4 * Cout), fl)
+        _, _, x3 = ops.ctrgc_fwd(S(x), pq, W3, B3, W4, B4, A, al, Cin, Cout, S_, R, stats=True, keep_x3=True)
         dy = r(N, Cout, T, V); ypre = r(N, Cout, T, V); cb = r(3, Cout)
-        us = timeit(lambda: ops.ctrgc_bwd(S(x), pq, W3, B3, W4, B4, A, al, Cin, Cout, S_, R, S(dy, ypre, cb)))
-        rep('ctrgc_bwd (dx3+de+reduces) ' + nm, us, 4.0 * N * T * V * (Cin + 4 * Cout + 3 * Cout), 2 * fl)
+        ca = (S(x), pq, W3, B3, W4, B4, A, al, Cin, Cout, S_, R, S(dy, ypre, cb))
+        us = timeit(lambda: ops.ctrgc_bwd_dx3(*ca))
+        rep('ctrgc_bwd_dx3 ' + nm, us, 4.0 * N * T * V * (2 * Cout + 3 * Cout), N * S_ * (2.0 * R * Cout * V * V + 2.0 * Cout * T * V * V))
+        us = timeit(lambda: ops.ctrgc_bwd_de(*ca))
+        rep('ctrgc_bwd_de recompute ' + nm, us, 4.0 * N * T * V * (Cin + 2 * Cout), fl)
+        us = timeit(lambda: ops.ctrgc_bwd_de(*ca, x3=x3))
+        rep('ctrgc_bwd_de stored x3 ' + nm, us, 4.0 * N * T * V * (2 * Cout + 3 * Cout), N * S_ * (2.0 * R * Cout * V * V + 2.0 * Cout * T * V * V))
 
 if not only or 'ew' in only:
     for C_, T in [(64, 64), (256, 16)]:

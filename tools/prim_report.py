@@ -47,7 +47,7 @@ def run(N, Cin, Cout, T, V, S_):
     xb = ops.tmean(xs, Cin)
     pq, _ = ops.conv(S(xb.view(1, Cin, N, V)), K=Cin, w=t(W12), bias=t(B12), M=S_ * 2 * R)
     pq = pq.view(S_ * 2 * R, N, V)
-    yg, part = ops.ctrgc_fwd(xs, pq, t(W3), t(B3), t(W4), t(B4), t(A), t(alpha), Cin, Cout, S_, R, stats=True)
+    yg, part, x3k = ops.ctrgc_fwd(xs, pq, t(W3), t(B3), t(W4), t(B4), t(A), t(alpha), Cin, Cout, S_, R, stats=True)
     dx3, db3, dA, dW4, db4, dal, dpq = ops.ctrgc_bwd(xs, pq, t(W3), t(B3), t(W4), t(B4), t(A), t(alpha),
                                                      Cin, Cout, S_, R, S(t(cot)))
     dW3 = ops.wgrad(S(dx3), xs, M=S_ * Cout, K=Cin)
