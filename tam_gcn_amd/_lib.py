@@ -96,16 +96,17 @@ def load():
     # our launches fail with "no ROCm-capable device".  Loading torch first makes the dynamic
     # loader satisfy our DT_NEEDED with torch's already-loaded runtime (same SONAME).
     import torch  # noqa: F401
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get('TAMGCN_LIB', LIB_PATH)      # instrumented side builds (tools/), same ABI
+    if not os.path.exists(path):
         raise TamgcnLibraryError(
-            f'{LIB_PATH} not found: the HIP extension is not built.  Run '
+            f'{path} not found: the HIP extension is not built.  Run '
             '`python -m tam_gcn_amd.build` (needs hipcc, gfx950).  There is no CPU fallback.')
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         try:
             fn = getattr(lib, name)
         except AttributeError as e:
-            raise TamgcnLibraryError(f'{LIB_PATH} does not export {name}') from e
+            raise TamgcnLibraryError(f'{path} does not export {name}') from e
         fn.restype = res
         fn.argtypes = args
     _lib = lib

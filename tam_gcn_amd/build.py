@@ -35,27 +35,29 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
-    if not force and not needs_build():
+def build(force=False, verbose=True, out=None, defines=()):
+    """out/defines: instrumented side builds for tools/ (e.g. -DTAMGCN_TRACE); the product is LIB."""
+    lib = out or LIB
+    if out is None and not force and not needs_build():
         return LIB
     objs = []
     procs = []
     for s in sources():
-        o = os.path.splitext(s)[0] + '.o'
+        o = os.path.splitext(s)[0] + ('.o' if out is None else '.side.o')
         objs.append(o)
-        cmd = [_hipcc(), f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-c', s, '-o', o]
+        cmd = [_hipcc(), f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', *[f'-D{d}' for d in defines], '-c', s, '-o', o]
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for cmd, p in procs:
         out, _ = p.communicate()
         if p.returncode:
             raise RuntimeError('hipcc failed: ' + ' '.join(cmd) + '\n' + out.decode(errors='replace'))
-    cmd = [_hipcc(), f'--offload-arch={ARCH}', '-shared', '-fPIC', '-o', LIB] + objs
+    cmd = [_hipcc(), f'--offload-arch={ARCH}', '-shared', '-fPIC', '-o', lib] + objs
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode:
         raise RuntimeError('link failed: ' + ' '.join(cmd) + '\n' + r.stdout.decode(errors='replace'))
     if verbose:
-        print(f'[tam_gcn_amd.build] built {LIB}')
-    return LIB
+        print(f'[tam_gcn_amd.build] built {lib}')
+    return lib
 
 
 if __name__ == '__main__':

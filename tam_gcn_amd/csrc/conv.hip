@@ -23,6 +23,15 @@ constexpr int MAXCW = 5;      // column tiles (16 wide) per wave  -> 4 waves * 5
 constexpr int MAXCOLS = 320;
 constexpr int NTHREADS = 256;
 
+#ifdef TAMGCN_TRACE   // tools/conv_phases.py: per-phase shader-clock totals of wave 0 of every workgroup
+__device__ unsigned long long tg_trace[16];
+#define TG_T(var) unsigned long long var = __builtin_amdgcn_s_memtime()
+#define TG_ACC(slot, expr) do { if (threadIdx.x == 0) atomicAdd(&tg_trace[slot], (unsigned long long)(expr)); } while (0)
+#else
+#define TG_T(var)
+#define TG_ACC(slot, expr)
+#endif
+
 struct ConvArgs {
     SrcDev src;
     int N, K, T_in, V;
@@ -235,6 +244,70 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel(const ConvArgs a) {
 // the current chunk run; the BatchNorm-apply prologue is applied on the way into LDS from a
 // per-channel coefficient table staged once per workgroup.
 // ---------------------------------------------------------------------------
+// Second half of the staged epilogue: rows r0..r0+RP-1 of the accumulator tile sit in LDS (Tt, pitch PT);
+// TPR threads walk one row in float4 steps: bias / broadcast / residual adds / mask / BatchNorm moments,
+// 16-byte coalesced loads and stores.  Row moments land in Ss[0..BMT) / Ss[4*BM..).
+template <int NTH>
+__device__ __forceinline__ void staged_rows(const ConvArgs& a, const float* Tt, int PT, int RP, int r0, int BMT, int m0, int n, int t0,
+                                            int nc4, float* Ss) {
+    const int tid = threadIdx.x, V = a.V;
+    const int TPR = NTH / RP;
+    const int row = tid / TPR, seg = tid - row * TPR;
+    const int m = m0 + r0 + row;
+    float p1 = 0.f, p2 = 0.f;
+    const bool rowok = r0 + row < BMT && m < a.M;   // RP may overshoot the tile (BMT = 48, RP = 32)
+    if (rowok) {
+        const float bia = a.bias ? a.bias[m] : 0.f;
+        const float ctr = a.aux ? a.aux_center[a.auxcoff + m] : 0.f;
+        const long long ybase = ((long long)n * a.yctot + a.ycoff + m) * a.T_y * V;
+        const long long mbase = a.has_mask ? ((long long)n * a.mask.ctot + a.mask.coff + m) * a.T_y * V : 0;
+        const long long abase = a.aux ? ((long long)n * a.auxctot + a.auxcoff + m) * a.T_y * V : 0;
+        float mc1 = 1.f, mc2 = 0.f, mc0 = 0.f;
+        if (a.has_mask && a.mask.coef) {
+            int mch = a.mask.coff + m;
+            mc1 = a.mask.coef[mch]; mc0 = a.mask.coef[2 * a.mask.ctot + mch];
+            if (a.mask.x2) mc2 = a.mask.coef[a.mask.ctot + mch];
+        }
+        for (int c4 = seg; c4 < nc4; c4 += TPR) {
+            const int col = c4 << 2;
+            const int fr = col / V, v = col - fr * V;
+            const long long off = (long long)(t0 + fr) * a.ostride * V + v;
+            float4 val = *reinterpret_cast<const float4*>(Tt + row * PT + col);
+            val.x += bia; val.y += bia; val.z += bia; val.w += bia;
+            if (a.bcast) {
+                float4 b = *reinterpret_cast<const float4*>(a.bcast + ((long long)m * a.N + n) * V + v);
+                val.x = fmaf(b.x, a.bcast_scale, val.x); val.y = fmaf(b.y, a.bcast_scale, val.y);
+                val.z = fmaf(b.z, a.bcast_scale, val.z); val.w = fmaf(b.w, a.bcast_scale, val.w);
+            }
+            if (a.add1) { float4 t = *reinterpret_cast<const float4*>(a.add1 + ybase + off); val.x += t.x; val.y += t.y; val.z += t.z; val.w += t.w; }
+            if (a.add2) { float4 t = *reinterpret_cast<const float4*>(a.add2 + ybase + off); val.x += t.x; val.y += t.y; val.z += t.z; val.w += t.w; }
+            if (a.has_mask) {
+                float4 q = *reinterpret_cast<const float4*>(a.mask.x1 + mbase + off);
+                float4 q2 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a.mask.x2) q2 = *reinterpret_cast<const float4*>(a.mask.x2 + mbase + off);
+                if (!(fmaf(mc1, q.x, fmaf(mc2, q2.x, mc0)) > 0.f)) val.x = 0.f;
+                if (!(fmaf(mc1, q.y, fmaf(mc2, q2.y, mc0)) > 0.f)) val.y = 0.f;
+                if (!(fmaf(mc1, q.z, fmaf(mc2, q2.z, mc0)) > 0.f)) val.z = 0.f;
+                if (!(fmaf(mc1, q.w, fmaf(mc2, q2.w, mc0)) > 0.f)) val.w = 0.f;
+            }
+            if (a.stats_part) {
+                float4 x2 = val;
+                if (a.aux) {
+                    x2 = *reinterpret_cast<const float4*>(a.aux + abase + off);
+                    x2.x -= ctr; x2.y -= ctr; x2.z -= ctr; x2.w -= ctr;
+                }
+                p1 += (val.x + val.y) + (val.z + val.w);
+                p2 = fmaf(val.x, x2.x, fmaf(val.y, x2.y, fmaf(val.z, x2.z, fmaf(val.w, x2.w, p2))));
+            }
+            *reinterpret_cast<float4*>(a.y + ybase + off) = val;
+        }
+    }
+    if (a.stats_part) {
+        for (int o = 1; o < TPR; o <<= 1) { p1 += __shfl_xor(p1, o); p2 += __shfl_xor(p2, o); }
+        if (seg == 0 && rowok) { Ss[r0 + row] = p1; Ss[4 * BM + r0 + row] = p2; }
+    }
+}
+
 template <int BKV, int MT, int CWT>
 __global__ __launch_bounds__(NTHREADS) void conv_kernel_vec(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -325,12 +398,20 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel_vec(const ConvArgs a) {
             }
         }
     };
+    TG_T(tt0);
     prefetch(0);
     __syncthreads();                                   // cf table visible
+    TG_T(tt1); TG_ACC(0, tt1 - tt0);
 
     const float* arow = As + j * BKVP + kq;
     for (int k0 = 0; k0 < a.K; k0 += BKV) {
+        TG_T(ta);
         __syncthreads();                               // previous chunk's MFMAs done with As/Bs
+        TG_T(tb); TG_ACC(1, tb - ta);
+#ifdef TAMGCN_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        TG_T(tw); TG_ACC(2, tw - tb);
         const int nA = a.KT * BMT * BKV;
         if (apf) {
 #pragma unroll
@@ -375,8 +456,11 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel_vec(const ConvArgs a) {
                 *reinterpret_cast<float4*>(Bs + p_lds[i]) = o;
             }
         }
+        TG_T(tc); TG_ACC(3, tc - tw);
         __syncthreads();
+        TG_T(td); TG_ACC(4, td - tc);
         if (k0 + BKV < a.K) prefetch(k0 + BKV);        // in flight under the MFMAs below
+        TG_T(te); TG_ACC(5, te - td);
         for (int tap = 0; tap < a.KT; ++tap) {         // branch-free MFMA block: MT x CWT tiles per k-step
             const float* at = arow + tap * BMT * BKVP;
             const float* bt_ = Bs + kq * a.pitchB + tap * a.dil * V;
@@ -393,7 +477,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel_vec(const ConvArgs a) {
                     for (int mt = 0; mt < MT; ++mt) acc[mt][c] = mfma16(av[mt], bv[c], acc[mt][c]);
             }
         }
+        TG_T(tf); TG_ACC(6, tf - te);
     }
+    TG_T(tg0);
 
     // ---- epilogue.  The accumulators are staged through LDS (the operand tiles are dead) and
     // a compact loop finishes one float4 per iteration: bias / broadcast / residual adds / mask /
@@ -406,7 +492,6 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel_vec(const ConvArgs a) {
     int RP = (avail / PT) & ~15;                       // rows per pass: 16, 32, 48 or 64 (host checks >= 16)
     if (RP > BMT) RP = BMT;
     if (RP == 48) RP = 32;
-    const int TPR = NTHREADS / RP;                     // threads per row: 16, 8 or 4
     const int nc4 = ncols >> 2;
     if (a.stats_part) {
         for (int e = tid; e < 2 * 4 * BM; e += NTHREADS) Ss[e] = 0.f;
@@ -426,60 +511,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel_vec(const ConvArgs a) {
             }
         }
         __syncthreads();
-        const int row = tid / TPR, seg = tid - row * TPR;
-        const int m = m0 + r0 + row;
-        float p1 = 0.f, p2 = 0.f;
-        const bool rowok = r0 + row < BMT && m < a.M;   // RP may overshoot the tile (BMT = 48, RP = 32)
-        if (rowok) {
-            const float bia = a.bias ? a.bias[m] : 0.f;
-            const float ctr = a.aux ? a.aux_center[a.auxcoff + m] : 0.f;
-            const long long ybase = ((long long)n * a.yctot + a.ycoff + m) * a.T_y * V;
-            const long long mbase = a.has_mask ? ((long long)n * a.mask.ctot + a.mask.coff + m) * a.T_y * V : 0;
-            const long long abase = a.aux ? ((long long)n * a.auxctot + a.auxcoff + m) * a.T_y * V : 0;
-            float mc1 = 1.f, mc2 = 0.f, mc0 = 0.f;
-            if (a.has_mask && a.mask.coef) {
-                int mch = a.mask.coff + m;
-                mc1 = a.mask.coef[mch]; mc0 = a.mask.coef[2 * a.mask.ctot + mch];
-                if (a.mask.x2) mc2 = a.mask.coef[a.mask.ctot + mch];
-            }
-            for (int c4 = seg; c4 < nc4; c4 += TPR) {
-                const int col = c4 << 2;
-                const int fr = col / V, v = col - fr * V;
-                const long long off = (long long)(t0 + fr) * a.ostride * V + v;
-                float4 val = *reinterpret_cast<const float4*>(Tt + row * PT + col);
-                val.x += bia; val.y += bia; val.z += bia; val.w += bia;
-                if (a.bcast) {
-                    float4 b = *reinterpret_cast<const float4*>(a.bcast + ((long long)m * a.N + n) * V + v);
-                    val.x = fmaf(b.x, a.bcast_scale, val.x); val.y = fmaf(b.y, a.bcast_scale, val.y);
-                    val.z = fmaf(b.z, a.bcast_scale, val.z); val.w = fmaf(b.w, a.bcast_scale, val.w);
-                }
-                if (a.add1) { float4 t = *reinterpret_cast<const float4*>(a.add1 + ybase + off); val.x += t.x; val.y += t.y; val.z += t.z; val.w += t.w; }
-                if (a.add2) { float4 t = *reinterpret_cast<const float4*>(a.add2 + ybase + off); val.x += t.x; val.y += t.y; val.z += t.z; val.w += t.w; }
-                if (a.has_mask) {
-                    float4 q = *reinterpret_cast<const float4*>(a.mask.x1 + mbase + off);
-                    float4 q2 = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (a.mask.x2) q2 = *reinterpret_cast<const float4*>(a.mask.x2 + mbase + off);
-                    if (!(fmaf(mc1, q.x, fmaf(mc2, q2.x, mc0)) > 0.f)) val.x = 0.f;
-                    if (!(fmaf(mc1, q.y, fmaf(mc2, q2.y, mc0)) > 0.f)) val.y = 0.f;
-                    if (!(fmaf(mc1, q.z, fmaf(mc2, q2.z, mc0)) > 0.f)) val.z = 0.f;
-                    if (!(fmaf(mc1, q.w, fmaf(mc2, q2.w, mc0)) > 0.f)) val.w = 0.f;
-                }
-                if (a.stats_part) {
-                    float4 x2 = val;
-                    if (a.aux) {
-                        x2 = *reinterpret_cast<const float4*>(a.aux + abase + off);
-                        x2.x -= ctr; x2.y -= ctr; x2.z -= ctr; x2.w -= ctr;
-                    }
-                    p1 += (val.x + val.y) + (val.z + val.w);
-                    p2 = fmaf(val.x, x2.x, fmaf(val.y, x2.y, fmaf(val.z, x2.z, fmaf(val.w, x2.w, p2))));
-                }
-                *reinterpret_cast<float4*>(a.y + ybase + off) = val;
-            }
-        }
-        if (a.stats_part) {
-            for (int o = 1; o < TPR; o <<= 1) { p1 += __shfl_xor(p1, o); p2 += __shfl_xor(p2, o); }
-            if (seg == 0 && rowok) { Ss[r0 + row] = p1; Ss[4 * BM + r0 + row] = p2; }
-        }
+        staged_rows<NTHREADS>(a, Tt, PT, RP, r0, BMT, m0, n, t0, nc4, Ss);
     }
     if (a.stats_part) {
         __syncthreads();
@@ -492,6 +524,205 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel_vec(const ConvArgs a) {
             }
         }
     }
+}
+
+
+// ===========================================================================
+// 1x1, stride-1 convolution = a GEMM  Y[m][p] = sum_k W[m][k] act(X[k][p])  whose columns p = (t, v)
+// are contiguous per channel.  Both operands reach LDS by LDS-DMA (global_load_lds): no VGPR round
+// trip, no staging VALU, no ds_write pass -- the register-staged kernel above spent as long issuing
+// loads and writing LDS as in its MFMAs (tools/conv_phases.py).  A ring of NST stages keeps two chunks
+// in flight across ONE raw s_barrier per chunk (counted vmcnt, never 0 in the loop).
+//
+//   workgroup   512 threads = 8 waves as 2 (rows) x 4 (columns); tile 64 channels x BT frames (<= 320 cols)
+//   B image     [BK][LB] floats per source, lane-linear per 4-row group (5 x 1 KB pieces at LB = 320);
+//               odd k rows are rotated by 16 columns ON THE SOURCE ADDRESS, so the two k rows a 32-lane
+//               half reads sit 16 banks apart (LB == 0 mod 32: conflict-free)
+//   A image     [BK][PA = 80]: one dword LDS-DMA per k row, lane = output channel (pitch == 16 mod 32)
+//   prologue    BatchNorm(-backward) apply / two-source combine / ReLU happen at the fragment read:
+//               each B element is read by exactly one wave, so this costs 1-3 VALU per element
+//   epilogue    the staged float4 epilogue of conv_kernel_vec (staged_rows)
+// ===========================================================================
+constexpr int G_NT = 512, G_BMT = 64, G_PA = 80, G_PBMAX = 320, G_NST = 3, G_CWT = 5, G_MT = 2;
+
+typedef __attribute__((address_space(1))) const void* tg_gptr;
+typedef __attribute__((address_space(3))) void* tg_lptr;
+
+#define TG_VMCNT_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+__device__ __forceinline__ void wait_vmcnt(int n) {     // n is wave-uniform
+    switch (n) {
+        TG_VMCNT_CASE(0) TG_VMCNT_CASE(1) TG_VMCNT_CASE(2) TG_VMCNT_CASE(3) TG_VMCNT_CASE(4)
+        TG_VMCNT_CASE(5) TG_VMCNT_CASE(6) TG_VMCNT_CASE(7) TG_VMCNT_CASE(8)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+template <int NSRC, int BK>
+__global__ __launch_bounds__(G_NT, 2) void conv1x1_glds_kernel(const ConvArgs a, int ntt, int nmt) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int STG = BK * G_PBMAX * NSRC + BK * G_PA;          // floats per stage
+    constexpr int NAI = BK / 8;                                   // A pieces per wave and chunk
+    constexpr int MAXB = (NSRC * (BK / 4) * 5 + 7) / 8;           // B pieces per wave and chunk (upper bound)
+    float* cf = smem + G_NST * STG;                               // [3][K]
+    float* Ss = cf + 3 * a.K;                                     // [2][4*BM] row moments
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kq = lane >> 4, wm = wave >> 2, wn = wave & 3;
+    const int V = a.V, K = a.K, LB = a.LB;
+    // workgroup -> (sample, frame tile, channel tile); the channel tiles of one (n, tt) share an XCD's L2
+    int g, mtile;
+    {
+        const int L = blockIdx.x, ng = a.N * ntt;
+        if ((ng & 7) == 0) { const int xcd = L & 7, i = L >> 3; mtile = i % nmt; g = (i / nmt) * 8 + xcd; }
+        else { g = L / nmt; mtile = L - g * nmt; }
+    }
+    const int n = g / ntt, tt = g - n * ntt;
+    const int m0 = mtile * G_BMT, t0 = tt * a.BT;
+    const int bt = min(a.BT, a.T_out - t0);
+    const int ncols = bt * V;
+    const long long TV = (long long)a.T_in * V;
+
+    for (int e = tid; e < K; e += G_NT) {
+        int ch = a.src.coff + e;
+        cf[e] = a.src.coef ? a.src.coef[ch] : 1.f;
+        cf[K + e] = (a.src.coef && a.src.x2) ? a.src.coef[a.src.ctot + ch] : 0.f;
+        cf[2 * K + e] = a.src.coef ? a.src.coef[2 * a.src.ctot + ch] : 0.f;
+    }
+
+    // ---- per-lane DMA descriptors (the same for every chunk)
+    const int NQ = (LB + 63) >> 6;                                // 1 KB pieces per 4-row group
+    const int NI1 = (BK / 4) * NQ;                                // pieces per source and chunk
+    int b_rel[MAXB], b_dst[MAXB];                                 // source offset (floats), LDS offset of the piece (floats)
+    bool b_ok[MAXB], b_on[MAXB];
+    int nissue = NAI;
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i) {
+        const int id = wave + i * 8;
+        const bool idok = id < NSRC * NI1;
+        const int src = idok ? id / NI1 : 0;
+        const int rem = id - src * NI1;
+        const int grp = rem / NQ, q = rem - grp * NQ;
+        const int f = q * 256 + lane * 4;                         // float index inside the 4-row group
+        const int r = f / LB, off = f - r * LB;
+        int col = off + ((r & 1) << 4);                           // source column of this LDS slot
+        if (col >= LB) col -= LB;
+        b_ok[i] = idok && r < 4 && col < ncols;
+        b_rel[i] = (int)((grp * 4 + r) * TV) + col + src * 0x40000000;   // bit 30 tags the second source
+        b_dst[i] = src * (BK * G_PBMAX) + grp * 4 * LB + q * 256;
+        b_on[i] = __ballot(b_ok[i]) != 0ull;                      // wave-uniform: the piece exists
+        nissue += b_on[i] ? 1 : 0;
+    }
+    const float* xb1 = a.src.x1 + ((long long)n * a.src.ctot + a.src.coff) * TV + (long long)t0 * V;
+    const float* xb2 = NSRC == 2 ? a.src.x2 + ((long long)n * a.src.ctot + a.src.coff) * TV + (long long)t0 * V : nullptr;
+    const bool a_ok = m0 + lane < a.M;
+    const float* wbase = a.w + (long long)(m0 + lane) * a.ws_m + a.w_off;
+
+    auto issue = [&](int c) {
+        float* st = smem + (c % G_NST) * STG;
+        const int k0 = c * BK;
+#pragma unroll
+        for (int i = 0; i < NAI; ++i) {
+            const int ka = wave * NAI + i;
+            if (a_ok) __builtin_amdgcn_global_load_lds((tg_gptr)(wbase + (long long)(k0 + ka) * a.ws_k),
+                                                       (tg_lptr)(st + BK * G_PBMAX * NSRC + ka * G_PA), 4, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < MAXB; ++i) {
+            if (b_on[i]) {
+                const float* base = (NSRC == 2 && (b_rel[i] & 0x40000000)) ? xb2 : xb1;
+                const float* gp = base + (long long)k0 * TV + (b_rel[i] & 0x3fffffff);
+                if (b_ok[i]) __builtin_amdgcn_global_load_lds((tg_gptr)gp, (tg_lptr)(st + b_dst[i]), 16, 0, 0);
+            }
+        }
+    };
+
+    // fragment addressing: this lane reads k rows of parity kq&1 only
+    int bslot[G_CWT];
+#pragma unroll
+    for (int c = 0; c < G_CWT; ++c) {
+        int col = (wn * G_CWT + c) * 16 + j;
+        if (col >= ncols) col = 0;                                // padding tile: in-bounds data, never stored
+        int sl = col - ((kq & 1) << 4);
+        bslot[c] = sl < 0 ? sl + LB : sl;
+    }
+    f32x4 acc[G_MT][G_CWT];
+#pragma unroll
+    for (int mt = 0; mt < G_MT; ++mt)
+#pragma unroll
+        for (int c = 0; c < G_CWT; ++c) acc[mt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float lo = a.src.act == 1 ? 0.f : -__builtin_inff();
+
+    __syncthreads();                                              // cf visible (no DMA in flight yet)
+    const int nch = K / BK;
+    issue(0);
+    if (nch > 1) issue(1);
+    for (int c = 0; c < nch; ++c) {
+        wait_vmcnt(c + 1 < nch ? nissue : 0);                     // this wave's pieces of chunk c have landed
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // everyone's have; chunk c-1 fully consumed
+        if (c + 2 < nch) issue(c + 2);
+        const float* st = smem + (c % G_NST) * STG;
+        const float* As = st + BK * G_PBMAX * NSRC + wm * 32 + j;
+        const int k0 = c * BK;
+#pragma unroll
+        for (int k4 = 0; k4 < BK / 4; ++k4) {
+            const int k = k4 * 4 + kq;
+            float av[G_MT], bv[G_CWT];
+#pragma unroll
+            for (int mt = 0; mt < G_MT; ++mt) av[mt] = As[k * G_PA + mt * 16];
+            const float c1 = cf[k0 + k], c0 = cf[2 * K + k0 + k];
+            if constexpr (NSRC == 2) {
+                const float c2 = cf[K + k0 + k];
+#pragma unroll
+                for (int cc = 0; cc < G_CWT; ++cc) {
+                    float v1 = st[k * LB + bslot[cc]], v2 = st[BK * G_PBMAX + k * LB + bslot[cc]];
+                    bv[cc] = fmaxf(fmaf(c1, v1, fmaf(c2, v2, c0)), lo);
+                }
+            } else {
+#pragma unroll
+                for (int cc = 0; cc < G_CWT; ++cc) bv[cc] = fmaxf(fmaf(c1, st[k * LB + bslot[cc]], c0), lo);
+            }
+#pragma unroll
+            for (int cc = 0; cc < G_CWT; ++cc)
+#pragma unroll
+                for (int mt = 0; mt < G_MT; ++mt) acc[mt][cc] = mfma16(av[mt], bv[cc], acc[mt][cc]);
+        }
+    }
+
+    // ---- staged epilogue (two passes of 32 rows through the dead stage buffers)
+    constexpr int PT = G_CWT * 64 + 4, RP = 32;
+    float* Tt = smem;
+    const int nc4 = ncols >> 2;
+    if (a.stats_part) {
+        for (int e = tid; e < 2 * 4 * BM; e += G_NT) Ss[e] = 0.f;
+    }
+    for (int r0 = 0; r0 < G_BMT; r0 += RP) {
+        __syncthreads();
+        if (wm * 32 == r0) {
+#pragma unroll
+            for (int mt = 0; mt < G_MT; ++mt)
+#pragma unroll
+                for (int c = 0; c < G_CWT; ++c) {
+                    const int col = (wn * G_CWT + c) * 16 + j;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Tt[(mt * 16 + kq * 4 + r) * PT + col] = acc[mt][c][r];
+                }
+        }
+        __syncthreads();
+        staged_rows<G_NT>(a, Tt, PT, RP, r0, G_BMT, m0, n, t0, nc4, Ss);
+    }
+    if (a.stats_part) {
+        __syncthreads();
+        if (tid < 2 * G_BMT) {
+            int stt = tid / G_BMT, row = tid - stt * G_BMT;
+            int m = m0 + row;
+            if (m < a.M) a.stats_part[((long long)stt * a.stats_ctot + a.stats_coff + m) * a.nparts + g] = Ss[stt * 4 * BM + row];
+        }
+    }
+}
+
+template <int NSRC, int BK>
+constexpr size_t glds_lds_bytes(int K) {
+    return sizeof(float) * ((size_t)G_NST * (BK * G_PBMAX * NSRC + BK * G_PA) + 3 * (size_t)K + 2 * 4 * BM);
 }
 
 struct ConvPlan { int BT, CW, TIN, lstride, sB, LB, pitchB, ntt, bk, mt, cwt; bool vec; size_t lds; };
@@ -539,6 +770,17 @@ static int plan_conv(const tamgcn_conv_desc* d, ConvPlan* p) {
 
 }  // namespace
 
+#ifdef TAMGCN_TRACE
+extern "C" int tamgcn_trace_read(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(tg_trace), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(tg_trace), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
 extern "C" int tamgcn_conv_nparts(const tamgcn_conv_desc* d) {
     ConvPlan p;
     if (!d || plan_conv(d, &p)) return -1;
@@ -573,7 +815,28 @@ extern "C" int tamgcn_conv(const tamgcn_conv_desc* d, void* stream) {
     a.nparts = d->N * p.ntt;
     a.BT = p.BT; a.CW = p.CW; a.TIN = p.TIN; a.lstride = p.lstride; a.sB = p.sB; a.LB = p.LB; a.pitchB = p.pitchB;
     dim3 grid(p.ntt, ceil_div(d->M, BM), d->N);
-    if (p.vec) {
+    // 1x1 stride-1 convs whose rows are plain contiguous column ranges go to the LDS-DMA GEMM
+    const bool aligned16 = (((uintptr_t)d->src.x1 | (uintptr_t)(d->src.x2 ? d->src.x2 : d->src.x1)) & 15) == 0;
+    const bool glds = p.vec && d->KT == 1 && d->stride == 1 && d->up == 1 && d->ostride == 1 && d->pad == 0 &&
+                      d->T_in == d->T_out && d->T_y == d->T_out && d->K % 16 == 0 && p.LB >= 64 && p.LB <= G_PBMAX &&
+                      aligned16 && (long long)d->K * d->T_in * d->V < (1LL << 30);
+    if (glds) {
+        const int nmt = ceil_div(d->M, G_BMT);
+        const unsigned nblk = (unsigned)(d->N * p.ntt * nmt);
+        if (d->src.x2) {
+            static bool f2 = false;
+            const size_t lds = glds_lds_bytes<2, 8>(d->K);
+            if (!f2) { (void)hipFuncSetAttribute((const void*)conv1x1_glds_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); f2 = true; }
+            hipLaunchKernelGGL((conv1x1_glds_kernel<2, 8>), dim3(nblk), dim3(G_NT), lds, (hipStream_t)stream, a, p.ntt, nmt);
+            tamgcn_note_kernel("conv1x1_glds_kernel<2, 8>");
+        } else {
+            static bool f1 = false;
+            const size_t lds = glds_lds_bytes<1, 16>(d->K);
+            if (!f1) { (void)hipFuncSetAttribute((const void*)conv1x1_glds_kernel<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); f1 = true; }
+            hipLaunchKernelGGL((conv1x1_glds_kernel<1, 16>), dim3(nblk), dim3(G_NT), lds, (hipStream_t)stream, a, p.ntt, nmt);
+            tamgcn_note_kernel("conv1x1_glds_kernel<1, 16>");
+        }
+    } else if (p.vec) {
         dim3 gridv(p.ntt, ceil_div(d->M, 16 * p.mt), d->N);
 #define TG_CONV_CASE(BKV_, MT_, CW_)                                                                              \
         if (p.bk == BKV_ && p.mt == MT_ && p.cwt == CW_) {                                                         \
