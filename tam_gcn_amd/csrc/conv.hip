@@ -1104,6 +1104,199 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(const WgradArgs a) {
                 }
 }
 
+
+// ===========================================================================
+// 1x1 stride-1 weight gradient as an LDS-DMA "NT" GEMM:  dW[m][k] = sum_{n,p} gy(n,m,p) x(n,k,p),
+// p = (t, v) contiguous in both operands.
+//
+//   workgroup   512 threads = 8 waves as 2 (m) x 4 (k); tile (32*WMT) x (64*WKT) of dW, one n-split
+//   chunk       32 contraction indices; every operand row is 128 B = 8 slots of 16 B; one dwordx4
+//               LDS-DMA piece carries 8 rows (1 KB, lane-linear).  Slot u of row r is stored at slot
+//               u ^ (r & 7) (swizzle applied to the per-lane SOURCE address), which makes the ds_read_b128
+//               fragment reads below bank-conflict free.
+//   contraction MFMA step s of a 16-index block takes p = 4*kq + s: each lane covers four steps with one
+//               16-byte read per operand tile (the same permutation on both operands).
+//   prologue    per-ROW coefficients (BatchNorm(-backward) apply, two-source combine, ReLU) are lane
+//               constants here (lane = row), applied to the fragment registers
+//   pipeline    3-stage ring, two chunks in flight, counted vmcnt + one raw s_barrier per chunk
+// Requires T*V % 32 == 0 (no zero padding of the contraction axis is possible with masked DMA).
+// ===========================================================================
+constexpr int W_PC = 32, W_NST = 3, W_NT = 512;
+
+template <int WMT, int WKT, int NY, int NX>
+__global__ __launch_bounds__(W_NT, 2) void wgrad_glds_kernel(const WgradArgs a, int ntk, int ntm) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int BMW = 2 * WMT * 16, BKW = 4 * WKT * 16;
+    constexpr int RY = BMW * NY, RX = BKW * NX, ROWS = RY + RX;
+    constexpr int STG = ROWS * W_PC;                              // floats per stage
+    constexpr int NPIECE = ROWS / 8;                              // 1 KB pieces per chunk
+    constexpr int MAXP = (NPIECE + 7) / 8;                        // per wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kq = lane >> 4, wr = wave >> 2, wc = wave & 3;
+    int split, tile;
+    {
+        const int L = blockIdx.x, nt = ntk * ntm;
+        if ((a.nsplit & 7) == 0) { const int xcd = L & 7, i = L >> 3; tile = i % nt; split = (i / nt) * 8 + xcd; }
+        else { split = L / nt; tile = L - split * nt; }
+    }
+    const int k0 = (tile % ntk) * BKW, m0 = (tile / ntk) * BMW;
+    const int n_begin = split * a.n_per, n_end = min(a.N, n_begin + a.n_per);
+    const long long cs = (long long)a.T_out * a.V;               // == T_in * V
+    const int cps = (int)(cs / W_PC);                             // chunks per sample
+    const int nch = max(0, n_end - n_begin) * cps;
+
+    // ---- DMA descriptors.  Stage rows: [Y1 | Y2 | X1 | X2]; lane -> (row in piece, physical slot)
+    const int pr = lane >> 3, ps = lane & 7;
+    const int pu = ps ^ pr;                                       // logical 16-byte slot this lane fetches
+    const float* p_base[MAXP];
+    bool p_ok[MAXP], p_on[MAXP], p_isy[MAXP];
+    int p_dst[MAXP];
+    int nissue = 0;
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+        const int q = wave + i * 8;
+        const bool qok = q < NPIECE;
+        const int row0 = (qok ? q : 0) * 8;                       // first stage row of the piece
+        const bool isy = row0 < RY;
+        int img, r;                                               // image (0/1) and row inside the tile
+        if (isy) { img = row0 / BMW; r = row0 - img * BMW + pr; }
+        else { img = (row0 - RY) / BKW; r = row0 - RY - img * BKW + pr; }
+        const SrcDev& sd = isy ? a.gy : a.src;
+        const int ch = (isy ? m0 : k0) + r;
+        p_ok[i] = qok && ch < (isy ? a.M : a.K);
+        p_base[i] = (img == 0 ? sd.x1 : sd.x2) + (long long)(sd.coff + (p_ok[i] ? ch : 0)) * cs + pu * 4;
+        p_isy[i] = isy;
+        p_dst[i] = row0 * W_PC;
+        p_on[i] = __ballot(p_ok[i]) != 0ull;
+        nissue += p_on[i] ? 1 : 0;
+    }
+    const long long ystep = (long long)a.gy.ctot * cs, xstep = (long long)a.src.ctot * cs;
+    auto issue = [&](int c) {
+        float* st = smem + (c % W_NST) * STG;
+        const int nn = c / cps, pc = c - nn * cps;
+        const long long oy = (long long)(n_begin + nn) * ystep + (long long)pc * W_PC;
+        const long long ox = (long long)(n_begin + nn) * xstep + (long long)pc * W_PC;
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            if (p_on[i]) {
+                const float* gp = p_base[i] + (p_isy[i] ? oy : ox);
+                if (p_ok[i]) __builtin_amdgcn_global_load_lds((tg_gptr)gp, (tg_lptr)(st + p_dst[i]), 16, 0, 0);
+            }
+        }
+    };
+
+    // ---- per-lane row coefficients (lane j <-> row of each fragment tile)
+    float cy1[WMT], cy2[WMT], cy0[WMT], cx1[WKT], cx2[WKT], cx0[WKT];
+#pragma unroll
+    for (int x = 0; x < WMT; ++x) {
+        const int m = m0 + (wr * WMT + x) * 16 + j;
+        const bool ok = m < a.M && a.gy.coef;
+        const int ch = a.gy.coff + (m < a.M ? m : 0);
+        cy1[x] = ok ? a.gy.coef[ch] : 1.f;
+        cy2[x] = (ok && NY == 2) ? a.gy.coef[a.gy.ctot + ch] : 0.f;
+        cy0[x] = ok ? a.gy.coef[2 * a.gy.ctot + ch] : 0.f;
+    }
+#pragma unroll
+    for (int y = 0; y < WKT; ++y) {
+        const int k = k0 + (wc * WKT + y) * 16 + j;
+        const bool ok = k < a.K && a.src.coef;
+        const int ch = a.src.coff + (k < a.K ? k : 0);
+        cx1[y] = ok ? a.src.coef[ch] : 1.f;
+        cx2[y] = (ok && NX == 2) ? a.src.coef[a.src.ctot + ch] : 0.f;
+        cx0[y] = ok ? a.src.coef[2 * a.src.ctot + ch] : 0.f;
+    }
+    const float loy = a.gy.act == 1 ? 0.f : -__builtin_inff(), lox = a.src.act == 1 ? 0.f : -__builtin_inff();
+
+    f32x4 acc[WMT][WKT];
+#pragma unroll
+    for (int x = 0; x < WMT; ++x)
+#pragma unroll
+        for (int y = 0; y < WKT; ++y) acc[x][y] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // fragment offsets inside a stage (floats): row * 32 + 4 * ((4b + kq) ^ (row & 7)), row & 7 == j & 7
+    const int yoff = ((wr * WMT) * 16 + j) * W_PC, xoff = (RY + (wc * WKT) * 16 + j) * W_PC;
+    const int sl0 = ((kq) ^ (j & 7)) * 4, sl1 = ((4 + kq) ^ (j & 7)) * 4;
+
+    if (nch > 0) issue(0);
+    if (nch > 1) issue(1);
+    for (int c = 0; c < nch; ++c) {
+        wait_vmcnt(c + 1 < nch ? nissue : 0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (c + 2 < nch) issue(c + 2);
+        const float* st = smem + (c % W_NST) * STG;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int sl = b ? sl1 : sl0;
+            f32x4 av[WMT], bv[WKT];
+#pragma unroll
+            for (int x = 0; x < WMT; ++x) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(st + yoff + x * 16 * W_PC + sl);
+                if constexpr (NY == 2) {
+                    f32x4 v2 = *reinterpret_cast<const f32x4*>(st + BMW * W_PC + yoff + x * 16 * W_PC + sl);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(cy1[x], v[e], fmaf(cy2[x], v2[e], cy0[x])), loy);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(cy1[x], v[e], cy0[x]), loy);
+                }
+                av[x] = v;
+            }
+#pragma unroll
+            for (int y = 0; y < WKT; ++y) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(st + xoff + y * 16 * W_PC + sl);
+                if constexpr (NX == 2) {
+                    f32x4 v2 = *reinterpret_cast<const f32x4*>(st + BKW * W_PC + xoff + y * 16 * W_PC + sl);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(cx1[y], v[e], fmaf(cx2[y], v2[e], cx0[y])), lox);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(cx1[y], v[e], cx0[y]), lox);
+                }
+                bv[y] = v;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int y = 0; y < WKT; ++y)
+#pragma unroll
+                    for (int x = 0; x < WMT; ++x) acc[x][y] = mfma16(av[x][e], bv[y][e], acc[x][y]);
+        }
+    }
+    float* out = a.part + (long long)split * a.M * a.K;
+#pragma unroll
+    for (int x = 0; x < WMT; ++x)
+#pragma unroll
+        for (int y = 0; y < WKT; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + (wr * WMT + x) * 16 + kq * 4 + r;
+                const int k = k0 + (wc * WKT + y) * 16 + j;
+                if (m < a.M && k < a.K) out[(long long)m * a.K + k] = acc[x][y][r];
+            }
+}
+
+template <int WMT, int WKT, int NY, int NX>
+static int launch_wgrad_glds(WgradArgs& a, hipStream_t s) {
+    constexpr int BMW = 2 * WMT * 16, BKW = 4 * WKT * 16;
+    const size_t lds = sizeof(float) * (size_t)W_NST * (BMW * NY + BKW * NX) * W_PC;
+    static bool flag = false;
+    if (!flag) { (void)hipFuncSetAttribute((const void*)wgrad_glds_kernel<WMT, WKT, NY, NX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); flag = true; }
+    a.n_per = ceil_div(a.N, a.nsplit);
+    const int ntk = ceil_div(a.K, BKW), ntm = ceil_div(a.M, BMW);
+    hipLaunchKernelGGL((wgrad_glds_kernel<WMT, WKT, NY, NX>), dim3((unsigned)(ntk * ntm * a.nsplit)), dim3(W_NT), lds, s, a, ntk, ntm);
+    tamgcn_note_kernel("wgrad_glds_kernel<%d, %d, %d, %d>", WMT, WKT, NY, NX);
+    return 0;
+}
+
+template <int WMT, int WKT>
+static int launch_wgrad_glds_src(WgradArgs& a, hipStream_t s) {
+    const bool y2 = a.gy.x2 != nullptr, x2 = a.src.x2 != nullptr;
+    if (y2 && x2) return launch_wgrad_glds<WMT, WKT, 2, 2>(a, s);
+    if (y2) return launch_wgrad_glds<WMT, WKT, 2, 1>(a, s);
+    if (x2) return launch_wgrad_glds<WMT, WKT, 1, 2>(a, s);
+    return launch_wgrad_glds<WMT, WKT, 1, 1>(a, s);
+}
+
 static inline int even_pitch(int n) {      // smallest p >= n with p == 2 (mod 4): conflict-free column reads, 8-byte rows
     int p = (n + 3) & ~3;
     return p + 2;
@@ -1186,9 +1379,28 @@ extern "C" int tamgcn_wgrad(const tamgcn_wgrad_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     int rc, wmt, wkt;
     wgrad_tile(d->M, d->K, d->KT, &wmt, &wkt);
+    const bool al16 = (((uintptr_t)d->gy.x1 | (uintptr_t)d->src.x1 | (uintptr_t)(d->gy.x2 ? d->gy.x2 : d->gy.x1) |
+                        (uintptr_t)(d->src.x2 ? d->src.x2 : d->src.x1)) & 15) == 0;
+    bool glds = d->KT == 1 && d->stride == 1 && d->pad == 0 && d->T_in == d->T_out && al16 &&
+                ((long long)d->T_out * d->V) % W_PC == 0;
+    if (glds) {              // three stages of both operands (every source) must fit the CU's LDS: shrink the tile
+        auto fits = [&](int tm, int tk) {
+            const size_t rows = (size_t)tm * 32 * (d->gy.x2 ? 2 : 1) + (size_t)tk * 32 * (d->src.x2 ? 2 : 1);
+            return sizeof(float) * W_NST * rows * W_PC <= 160 * 1024;
+        };
+        if (!fits(wmt, wkt) && wmt == 4) wmt = 2;
+        if (!fits(wmt, wkt) && wkt == 4) wkt = 2;
+        glds = fits(wmt, wkt);
+    }
     switch (d->KT) {
         case 1:
-            if (wmt == 2 && wkt == 2) rc = launch_wgrad<1, 2, 2>(a, s);
+            if (glds) {      // tile = 64 or 128 per side by the same rule as wgrad_tile (wmt: rows/32, wkt: cols/64)
+                if (wmt == 2 && wkt == 2) rc = launch_wgrad_glds_src<2, 1>(a, s);
+                else if (wmt == 4 && wkt == 2) rc = launch_wgrad_glds_src<4, 1>(a, s);
+                else if (wmt == 2 && wkt == 4) rc = launch_wgrad_glds_src<2, 2>(a, s);
+                else rc = launch_wgrad_glds_src<4, 2>(a, s);
+            }
+            else if (wmt == 2 && wkt == 2) rc = launch_wgrad<1, 2, 2>(a, s);
             else if (wmt == 4 && wkt == 2) rc = launch_wgrad<1, 4, 2>(a, s);
             else if (wmt == 2 && wkt == 4) rc = launch_wgrad<1, 2, 4>(a, s);
             else rc = launch_wgrad<1, 4, 4>(a, s);

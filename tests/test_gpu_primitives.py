@@ -73,6 +73,43 @@ def test_conv_fwd_bwd_wgrad(case):
     close(dw, w.grad, 1e-4, 2e-4, 'conv wgrad')
 
 
+@pytest.mark.parametrize('shape', [(3, 96, 64, 8, 20, True, False), (2, 192, 128, 16, 20, True, True),
+                                   (2, 64, 192, 32, 20, False, False), (5, 48, 40, 16, 20, False, True),
+                                   (2, 160, 160, 8, 20, True, True)])
+def test_pointwise_dma_gemms_with_prologue(shape):
+    """The LDS-DMA forms of the 1x1 conv and of its weight gradient (T*V % 32 == 0, K % 16 == 0) with
+    two-source BatchNorm(-backward)-apply operands, ReLU and channel slices; fp64 torch reference."""
+    from tam_gcn_amd import ops
+    from tam_gcn_amd.ops import S
+    N, M, K, T, V, ytwo, xtwo = shape
+    d = dev()
+    ap = lambda c, a, b: c[0][None, :, None, None] * a + (c[1][None, :, None, None] * b if b is not None else 0) + c[2][None, :, None, None]
+    Kt, Mt = K + 16, M + 32                                  # operands are channel slices of wider tensors
+    x1, x2 = rnd((N, Kt, T, V), 1), (rnd((N, Kt, T, V), 2) if xtwo else None)
+    cx = rnd((3, Kt), 3)
+    g1, g2 = rnd((N, Mt, T, V), 4), (rnd((N, Mt, T, V), 5) if ytwo else None)
+    cg = rnd((3, Mt), 6)
+    xv = torch.relu(ap(cx.double(), x1.double(), None if x2 is None else x2.double()))[:, 16:16 + K]
+    gv = ap(cg.double(), g1.double(), None if g2 is None else g2.double())[:, 32:32 + M]
+    t = lambda z: None if z is None else z.to(d)
+    xs = S(t(x1), t(x2), t(cx), coff=16, act=1)
+    gs = S(t(g1), t(g2), t(cg), coff=32)
+    dw = ops.wgrad(gs, xs, M=M, K=K)
+    ref = torch.einsum('nmtv,nktv->mk', gv, xv)
+    close(dw.view(M, K).double(), ref, 1e-4, 2e-4 * float(ref.abs().max()), 'wgrad (DMA)')
+    # forward conv on the prologue'd x, and the data-gradient form on the prologue'd gy
+    w = rnd((M, K, 1, 1), 7) * 0.1
+    b = rnd((M,), 8)
+    y, part = ops.conv(xs, K=K, w=t(w), bias=t(b), M=M, stats=True)
+    yr = torch.einsum('mk,nktv->nmtv', w[:, :, 0, 0].double(), xv) + b.double()[None, :, None, None]
+    close(y.double(), yr, 1e-4, 2e-4 * float(yr.abs().max()), 'conv fwd (DMA)')
+    close(part[0].sum(-1).double(), yr.sum((0, 2, 3)), 1e-3, 1e-2, 'stats')
+    a1 = rnd((N, K, T, V), 9)
+    dx, _ = ops.conv(gs, K=M, w=t(w), bias=None, M=K, wmode=1, add1=t(a1))
+    dxr = torch.einsum('mk,nmtv->nktv', w[:, :, 0, 0].double(), gv) + a1.double()
+    close(dx.double(), dxr, 1e-4, 2e-4 * float(dxr.abs().max()), 'conv bwd-data (DMA)')
+
+
 def test_conv_prologue_slices_mask_aux():
     from tam_gcn_amd import ops
     from tam_gcn_amd.ops import S
