@@ -116,6 +116,9 @@ typedef struct tamgcn_wgrad_desc {
     float* part;                    /* [nsplit][M][K][KT] */
     int nsplit;
 } tamgcn_wgrad_desc;
+/* Largest nsplit tamgcn_wgrad accepts for this descriptor: N, or more when the contraction can also be
+ * split inside a sample (1x1 stride-1 form).  Size `part` and nsplit from it. */
+int tamgcn_wgrad_max_split(const tamgcn_wgrad_desc* d);
 int tamgcn_wgrad(const tamgcn_wgrad_desc* d, void* stream);
 
 /* out[e] = (accumulate ? out[e] : 0) + scale * sum_{s<nsplit} part[s*stride_s + e]

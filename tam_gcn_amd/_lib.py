@@ -56,6 +56,7 @@ SIGNATURES = {
     'tamgcn_ctrgc_lds_bytes': (_i, [_i, _i, _i]),
     'tamgcn_conv_nparts': (_i, [C.POINTER(ConvDesc)]),
     'tamgcn_conv': (_i, [C.POINTER(ConvDesc), _p]),
+    'tamgcn_wgrad_max_split': (_i, [C.POINTER(WgradDesc)]),
     'tamgcn_wgrad': (_i, [C.POINTER(WgradDesc), _p]),
     'tamgcn_reduce_sum': (_i, [_p, _i, _ll, _ll, _f, _i, _p, _p]),
     'tamgcn_bn_fwd_finalize': (_i, [_p, _i, _i, _i, _d, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _i, _i, _i, _p]),

@@ -1140,10 +1140,10 @@ __global__ __launch_bounds__(W_NT, 2) void wgrad_glds_kernel(const WgradArgs a, 
         else { split = L / nt; tile = L - split * nt; }
     }
     const int k0 = (tile % ntk) * BKW, m0 = (tile / ntk) * BMW;
-    const int n_begin = split * a.n_per, n_end = min(a.N, n_begin + a.n_per);
     const long long cs = (long long)a.T_out * a.V;               // == T_in * V
     const int cps = (int)(cs / W_PC);                             // chunks per sample
-    const int nch = max(0, n_end - n_begin) * cps;
+    // a split owns a contiguous range of the (n, chunk) sequence: splits may be finer than samples
+    const int c_begin = split * a.n_per, nch = max(0, min(a.N * cps, c_begin + a.n_per) - c_begin);
 
     // ---- DMA descriptors.  Stage rows: [Y1 | Y2 | X1 | X2]; lane -> (row in piece, physical slot)
     const int pr = lane >> 3, ps = lane & 7;
@@ -1173,9 +1173,9 @@ __global__ __launch_bounds__(W_NT, 2) void wgrad_glds_kernel(const WgradArgs a, 
     const long long ystep = (long long)a.gy.ctot * cs, xstep = (long long)a.src.ctot * cs;
     auto issue = [&](int c) {
         float* st = smem + (c % W_NST) * STG;
-        const int nn = c / cps, pc = c - nn * cps;
-        const long long oy = (long long)(n_begin + nn) * ystep + (long long)pc * W_PC;
-        const long long ox = (long long)(n_begin + nn) * xstep + (long long)pc * W_PC;
+        const int gc = c_begin + c, nn = gc / cps, pc = gc - nn * cps;
+        const long long oy = (long long)nn * ystep + (long long)pc * W_PC;
+        const long long ox = (long long)nn * xstep + (long long)pc * W_PC;
 #pragma unroll
         for (int i = 0; i < MAXP; ++i) {
             if (p_on[i]) {
@@ -1281,7 +1281,7 @@ static int launch_wgrad_glds(WgradArgs& a, hipStream_t s) {
     const size_t lds = sizeof(float) * (size_t)W_NST * (BMW * NY + BKW * NX) * W_PC;
     static bool flag = false;
     if (!flag) { (void)hipFuncSetAttribute((const void*)wgrad_glds_kernel<WMT, WKT, NY, NX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); flag = true; }
-    a.n_per = ceil_div(a.N, a.nsplit);
+    a.n_per = ceil_div(a.N * (int)(((long long)a.T_out * a.V) / W_PC), a.nsplit);   // chunks per split
     const int ntk = ceil_div(a.K, BKW), ntm = ceil_div(a.M, BMW);
     hipLaunchKernelGGL((wgrad_glds_kernel<WMT, WKT, NY, NX>), dim3((unsigned)(ntk * ntm * a.nsplit)), dim3(W_NT), lds, s, a, ntk, ntm);
     tamgcn_note_kernel("wgrad_glds_kernel<%d, %d, %d, %d>", WMT, WKT, NY, NX);
@@ -1366,32 +1366,47 @@ __global__ __launch_bounds__(256) void reduce_sum_kernel(const float* part, int 
 
 }  // namespace
 
+// the LDS-DMA form applies (and with which tile) -- shared by tamgcn_wgrad and tamgcn_wgrad_max_split
+static bool wgrad_glds_plan(const tamgcn_wgrad_desc* d, int* wmt, int* wkt) {
+    wgrad_tile(d->M, d->K, d->KT, wmt, wkt);
+    const bool al16 = (((uintptr_t)d->gy.x1 | (uintptr_t)d->src.x1 | (uintptr_t)(d->gy.x2 ? d->gy.x2 : d->gy.x1) |
+                        (uintptr_t)(d->src.x2 ? d->src.x2 : d->src.x1)) & 15) == 0;
+    bool glds = d->KT == 1 && d->stride == 1 && d->pad == 0 && d->T_in == d->T_out && al16 &&
+                ((long long)d->T_out * d->V) % W_PC == 0;
+    if (!glds) return false;
+    // three stages of both operands (every source) must fit the CU's LDS: shrink the tile
+    auto fits = [&](int tm, int tk) {
+        const size_t rows = (size_t)tm * 32 * (d->gy.x2 ? 2 : 1) + (size_t)tk * 32 * (d->src.x2 ? 2 : 1);
+        return sizeof(float) * W_NST * rows * W_PC <= 160 * 1024;
+    };
+    if (!fits(*wmt, *wkt) && *wmt == 4) *wmt = 2;
+    if (!fits(*wmt, *wkt) && *wkt == 4) *wkt = 2;
+    return fits(*wmt, *wkt);
+}
+
+extern "C" int tamgcn_wgrad_max_split(const tamgcn_wgrad_desc* d) {
+    if (!d || d->N <= 0 || d->T_out <= 0 || d->V <= 0) return -1;
+    int wmt, wkt;
+    if (!wgrad_glds_plan(d, &wmt, &wkt)) return d->N;
+    const long long chunks = (long long)d->N * (((long long)d->T_out * d->V) / W_PC);
+    const long long m = chunks / 8;                      // at least 8 chunks of 32 per workgroup
+    return (int)(m < d->N ? d->N : (m > 65535 ? 65535 : m));
+}
+
 extern "C" int tamgcn_wgrad(const tamgcn_wgrad_desc* d, void* stream) {
     TG_CHECK(d && d->gy.x1 && d->src.x1 && d->part, "tamgcn_wgrad: null pointer");
     TG_CHECK(d->N > 0 && d->M > 0 && d->K > 0 && d->T_in > 0 && d->T_out > 0 && d->V > 0 && d->nsplit > 0,
              "tamgcn_wgrad: bad dims");
     TG_CHECK(d->gy.coff + d->M <= d->gy.ctot && d->src.coff + d->K <= d->src.ctot, "tamgcn_wgrad: channel slice out of range");
-    TG_CHECK(d->nsplit <= d->N && d->nsplit <= 65535, "tamgcn_wgrad: nsplit=%d out of range", d->nsplit);
+    TG_CHECK(d->nsplit <= tamgcn_wgrad_max_split(d), "tamgcn_wgrad: nsplit=%d exceeds tamgcn_wgrad_max_split=%d", d->nsplit,
+             tamgcn_wgrad_max_split(d));
     WgradArgs a;
     a.gy = make_src(d->gy); a.src = make_src(d->src);
     a.N = d->N; a.M = d->M; a.K = d->K; a.T_in = d->T_in; a.T_out = d->T_out; a.V = d->V;
     a.dil = d->dil; a.stride = d->stride; a.pad = d->pad; a.part = d->part; a.nsplit = d->nsplit;
     hipStream_t s = (hipStream_t)stream;
     int rc, wmt, wkt;
-    wgrad_tile(d->M, d->K, d->KT, &wmt, &wkt);
-    const bool al16 = (((uintptr_t)d->gy.x1 | (uintptr_t)d->src.x1 | (uintptr_t)(d->gy.x2 ? d->gy.x2 : d->gy.x1) |
-                        (uintptr_t)(d->src.x2 ? d->src.x2 : d->src.x1)) & 15) == 0;
-    bool glds = d->KT == 1 && d->stride == 1 && d->pad == 0 && d->T_in == d->T_out && al16 &&
-                ((long long)d->T_out * d->V) % W_PC == 0;
-    if (glds) {              // three stages of both operands (every source) must fit the CU's LDS: shrink the tile
-        auto fits = [&](int tm, int tk) {
-            const size_t rows = (size_t)tm * 32 * (d->gy.x2 ? 2 : 1) + (size_t)tk * 32 * (d->src.x2 ? 2 : 1);
-            return sizeof(float) * W_NST * rows * W_PC <= 160 * 1024;
-        };
-        if (!fits(wmt, wkt) && wmt == 4) wmt = 2;
-        if (!fits(wmt, wkt) && wkt == 4) wkt = 2;
-        glds = fits(wmt, wkt);
-    }
+    const bool glds = wgrad_glds_plan(d, &wmt, &wkt);
     switch (d->KT) {
         case 1:
             if (glds) {      // tile = 64 or 128 per side by the same rule as wgrad_tile (wmt: rows/32, wkt: cols/64)

@@ -103,14 +103,14 @@ def wgrad(gy, src, M, K, KT=1, dil=1, stride=1, pad=0):
     else:
         bm = bk = 32 if (M <= 32 and K <= 32) else 64
     tiles = ((M + bm - 1) // bm) * ((K + bk - 1) // bk)
-    nsplit = max(1, min(N, (1024 + tiles - 1) // tiles))
-    part = empty(nsplit, M, K, KT, like=gy.x1)
     d = WgradDesc()
     d.gy, d.src = gy.c(), src.c()
     d.N, d.M, d.K, d.T_in, d.T_out, d.V = N, M, K, T_in, T_out, V
     d.KT, d.dil, d.stride, d.pad = KT, dil, stride, pad
-    d.part, d.nsplit = _ptr(part), nsplit
     lib = _lib_()
+    nsplit = max(1, min(lib.tamgcn_wgrad_max_split(C.byref(d)), (1024 + tiles - 1) // tiles))
+    part = empty(nsplit, M, K, KT, like=gy.x1)
+    d.part, d.nsplit = _ptr(part), nsplit
     _lib.check(lib.tamgcn_wgrad(C.byref(d), _stream()), 'tamgcn_wgrad')
     if nsplit == 1:
         return part.view(M, K, KT, 1)

@@ -75,7 +75,7 @@ def test_conv_fwd_bwd_wgrad(case):
 
 @pytest.mark.parametrize('shape', [(3, 96, 64, 8, 20, True, False), (2, 192, 128, 16, 20, True, True),
                                    (2, 64, 192, 32, 20, False, False), (5, 48, 40, 16, 20, False, True),
-                                   (2, 160, 160, 8, 20, True, True)])
+                                   (2, 160, 160, 8, 20, True, True), (1, 48, 64, 72, 20, True, False)])
 def test_pointwise_dma_gemms_with_prologue(shape):
     """The LDS-DMA forms of the 1x1 conv and of its weight gradient (T*V % 32 == 0, K % 16 == 0) with
     two-source BatchNorm(-backward)-apply operands, ReLU and channel slices; fp64 torch reference."""
