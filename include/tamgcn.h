@@ -169,10 +169,16 @@ typedef struct tamgcn_ctrgc_desc {
     const float* b4;                /* [S][Cout] */
     const float* A;                 /* [S][V][V]      PA (or the A given to CTRGC.forward) */
     const float* alpha;             /* [1] device scalar */
+    const float* E;                 /* optional (N, S, Cout, V, V) from tamgcn_ctrgc_build_e: fwd / bwd_dx3 then load
+                                     * their E tiles instead of rebuilding them per channel tile; NULL = on chip */
 } tamgcn_ctrgc_desc;
 
+/* E[n,s,c,u,v] = alpha*(W4_s tanh(p_s[n,:,u] - q_s[n,:,v]) + b4_s)[c] + A_s[u,v] for every channel, once per
+ * layer and sample (R <= 32); pass it as d->E to tamgcn_ctrgc_fwd and tamgcn_ctrgc_bwd_dx3. */
+int tamgcn_ctrgc_build_e(const tamgcn_ctrgc_desc* d, float* E, void* stream);
+
 /* y[n,c,t,u] = sum_s sum_v E_s[n,c,u,v] * (W3_s x + b3_s)[n,c,t,v],
- * E_s = alpha*(W4_s tanh(p_s[u]-q_s[v]) + b4_s) + A_s ; E lives only in LDS.
+ * E_s = alpha*(W4_s tanh(p_s[u]-q_s[v]) + b4_s) + A_s ; with d->E == NULL E lives only in LDS.
  * stats_part (optional): [2][Cout][N] partial (sum y, sum y^2) per sample.
  * x3_out (optional): (N, S*Cout, T, V) receives x3 = W3 x + b3 (the tile is in LDS anyway) so that
  * the backward need not recompute the GEMM; NULL keeps the forward write-minimal. */

@@ -43,7 +43,7 @@ class CtrgcDesc(C.Structure):
                 ('T', C.c_int), ('V', C.c_int),
                 ('x', Src),
                 ('pq', C.c_void_p), ('w3', C.c_void_p), ('b3', C.c_void_p), ('w4', C.c_void_p),
-                ('b4', C.c_void_p), ('A', C.c_void_p), ('alpha', C.c_void_p)]
+                ('b4', C.c_void_p), ('A', C.c_void_p), ('alpha', C.c_void_p), ('E', C.c_void_p)]
 
 
 # name -> (restype, argtypes); must list every symbol of include/tamgcn.h
@@ -62,6 +62,7 @@ SIGNATURES = {
     'tamgcn_bn_fwd_finalize': (_i, [_p, _i, _i, _i, _d, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _i, _i, _i, _p]),
     'tamgcn_bn_bwd_finalize': (_i, [_p, _i, _i, _i, _d, _p, _p, _i, _i, _i, _p, _p, _p, _p, _i, _i, _i, _p]),
     'tamgcn_tmean': (_i, [_SP, _i, _i, _i, _i, _p, _p]),
+    'tamgcn_ctrgc_build_e': (_i, [C.POINTER(CtrgcDesc), _p, _p]),
     'tamgcn_ctrgc_fwd': (_i, [C.POINTER(CtrgcDesc), _p, _p, _p, _p]),
     'tamgcn_ctrgc_bwd_dx3': (_i, [C.POINTER(CtrgcDesc), _SP, _p, _p, _p]),
     'tamgcn_ctrgc_bwd_de': (_i, [C.POINTER(CtrgcDesc), _SP, _p, _p, _p, _p, _p, _p]),

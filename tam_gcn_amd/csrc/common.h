@@ -93,3 +93,26 @@ __device__ __forceinline__ float fast_tanh(float x) {
     float e = __expf(2.f * x);
     return 1.f - __fdividef(2.f, e + 1.f);
 }
+
+// ---------------------------------------------------------------------------
+// phase tracing for tools/*_phases.py (side builds with -DTAMGCN_TRACE only): shader-clock stamps of
+// wave 0 of every workgroup, summed per slot; one table and one reader per translation unit.
+// ---------------------------------------------------------------------------
+#ifdef TAMGCN_TRACE
+#define TG_TRACE_DEFINE(READER)                                                                        \
+    __device__ unsigned long long tg_trace[16];                                                        \
+    extern "C" int READER(unsigned long long* out16, int reset) {                                      \
+        if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(tg_trace), sizeof(unsigned long long) * 16) != hipSuccess) return -1; \
+        if (reset) {                                                                                   \
+            unsigned long long z[16] = {0};                                                            \
+            if (hipMemcpyToSymbol(HIP_SYMBOL(tg_trace), z, sizeof(z)) != hipSuccess) return -1;        \
+        }                                                                                              \
+        return 0;                                                                                      \
+    }
+#define TG_T(var) unsigned long long var = __builtin_amdgcn_s_memtime()
+#define TG_ACC(slot, expr) do { if (threadIdx.x == 0) atomicAdd(&tg_trace[slot], (unsigned long long)(expr)); } while (0)
+#else
+#define TG_TRACE_DEFINE(READER)
+#define TG_T(var)
+#define TG_ACC(slot, expr)
+#endif

@@ -23,14 +23,7 @@ constexpr int MAXCW = 5;      // column tiles (16 wide) per wave  -> 4 waves * 5
 constexpr int MAXCOLS = 320;
 constexpr int NTHREADS = 256;
 
-#ifdef TAMGCN_TRACE   // tools/conv_phases.py: per-phase shader-clock totals of wave 0 of every workgroup
-__device__ unsigned long long tg_trace[16];
-#define TG_T(var) unsigned long long var = __builtin_amdgcn_s_memtime()
-#define TG_ACC(slot, expr) do { if (threadIdx.x == 0) atomicAdd(&tg_trace[slot], (unsigned long long)(expr)); } while (0)
-#else
-#define TG_T(var)
-#define TG_ACC(slot, expr)
-#endif
+TG_TRACE_DEFINE(tamgcn_trace_read)
 
 struct ConvArgs {
     SrcDev src;
@@ -770,16 +763,6 @@ static int plan_conv(const tamgcn_conv_desc* d, ConvPlan* p) {
 
 }  // namespace
 
-#ifdef TAMGCN_TRACE
-extern "C" int tamgcn_trace_read(unsigned long long* out16, int reset) {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(tg_trace), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
-    if (reset) {
-        unsigned long long z[16] = {0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(tg_trace), z, sizeof(z)) != hipSuccess) return -1;
-    }
-    return 0;
-}
-#endif
 
 extern "C" int tamgcn_conv_nparts(const tamgcn_conv_desc* d) {
     ConvPlan p;

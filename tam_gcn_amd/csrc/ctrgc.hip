@@ -22,6 +22,8 @@
 // and discarded): per-MFMA guards made hipcc serialise every ds_read/MFMA pair.
 #include "common.h"
 
+TG_TRACE_DEFINE(tamgcn_trace_read_ctrgc)
+
 namespace {
 
 constexpr int CT = 16;          // channels per workgroup
@@ -33,6 +35,7 @@ struct CtrgcArgs {
     const float* x; int x_ctot, x_coff;
     const float* pq; const float* w3; const float* b3; const float* w4; const float* b4;
     const float* A; const float* alpha;
+    const float* E;             // (N, S, Cout, V*V) from tamgcn_ctrgc_build_e, or null: build the tiles on chip
     int nct;                    // Cout / CT
     int pitchB;                 // LDS pitch of the staged x chunk
     int regionB;                // floats of the shared "B" region (x3 tile / stage / D scratch)
@@ -102,43 +105,214 @@ __device__ __forceinline__ void fill_D(const CtrgcArgs& a, int n, int s, int r0,
 template <class G>
 __device__ void build_E(const CtrgcArgs& a, int n, int c0, float* Es, float* Dbuf, int region, bool transpose) {
     constexpr int V = G::V, VV = G::VV, NT = G::NT, NW = G::NW;
-    constexpr int NTILE = (VV + 15) / 16;
+    constexpr int NTILE = (VV + 15) / 16, NIT = (NTILE + NW - 1) / NW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kq = lane >> 4;
     const float alpha = a.alpha[0];
-    int RC = min(a.R, region / VV) & ~3;              // multiple of 4 (R is 8, 16, 32, ...)
-    if (RC < 4) RC = 4;
     const long long NV = (long long)a.N * V;
+    // p / q of this sample for every subset go to LDS in ONE batch of loads (the D fill used to pay an
+    // L2 round trip per four elements: 27 % of the forward kernel at C = 64, 60 % at C = 256).
+    const int per = 2 * a.R * V;                      // [p|q][r][v] of one subset
+    const bool all = region - ((a.S * per + 3) & ~3) >= 4 * VV;   // every subset at once, else one at a time
+    const int nst = ((all ? a.S * per : per) + 3) & ~3;
+    float* PQ = Dbuf + region - nst;
+    auto stage = [&](int s0, int cnt) {
+        constexpr int MAXL = 8;
+        for (int e0 = tid; e0 < cnt; e0 += MAXL * NT) {
+            float t[MAXL];
+#pragma unroll
+            for (int i = 0; i < MAXL; ++i) {
+                const int e = e0 + i * NT;
+                const int row = (e < cnt ? e : 0) / V, v = (e < cnt ? e : 0) - row * V;
+                t[i] = a.pq[((long long)s0 * 2 * a.R + row) * NV + (long long)n * V + v];
+            }
+#pragma unroll
+            for (int i = 0; i < MAXL; ++i) {
+                const int e = e0 + i * NT;
+                if (e < cnt) PQ[e] = t[i];
+            }
+        }
+    };
+    if (all) stage(0, a.S * per);
+    int RC = min(min(a.R, 16), (region - nst) / VV) & ~3;   // rel-channels per pass (<= 16: four A registers)
+    if (RC < 4) RC = 4;
     for (int s = 0; s < a.S; ++s) {
+        if (!all) { __syncthreads(); stage(s, per); }  // previous subset's passes are done with PQ
+        const float* Pp = PQ + (all ? s * per : 0);
+        const float* Qp = Pp + a.R * V;
         for (int r0 = 0; r0 < a.R; r0 += RC) {
             const int rc = min(RC, a.R - r0);
-            __syncthreads();
-            fill_D<G>(a, n, s, r0, rc, Dbuf);
-            __syncthreads();
-            const float* w4 = a.w4 + ((long long)s * a.Cout + c0 + j) * a.R + r0 + kq;
+            // Everything this pass needs from global memory is requested BEFORE the tanh fill and consumed
+            // after it: the W4 fragment, and on the last pass b4 and the A entries of this wave's tiles.
             const bool last = r0 + rc >= a.R;
-            for (int ct = wave; ct < NTILE; ct += NW) {
-                const int col = ct * 16 + j;
-                const int colc = col < VV ? col : 0;
-                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-                for (int k4 = 0; k4 < rc; k4 += 4)
-                    acc = mfma16(w4[k4], Dbuf[(k4 + kq) * VV + colc], acc);
-                if (col < VV) {
-                    const int u = col / V, v = col - u * V;
-                    const int off = transpose ? v * V + u : col;
+            float aw[4], b4r[4], Ar[NIT];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int c = kq * 4 + r;
-                        const int dst = (s * CT + c) * VV + off;
-                        float tot = acc[r] + (r0 == 0 ? 0.f : Es[dst]);
-                        if (last) tot = alpha * (tot + a.b4[s * a.Cout + c0 + c]) + a.A[s * VV + col];
-                        Es[dst] = tot;
+            for (int k = 0; k < 4; ++k)
+                aw[k] = (k * 4 + kq < rc) ? a.w4[((long long)s * a.Cout + c0 + j) * a.R + r0 + k * 4 + kq] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b4r[r] = last ? a.b4[s * a.Cout + c0 + kq * 4 + r] : 0.f;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int col = (wave + it * NW) * 16 + j;
+                Ar[it] = (last && col < VV) ? a.A[s * VV + col] : 0.f;
+            }
+            __syncthreads();                           // PQ staged / previous pass done with Dbuf
+            for (int e = tid; e < rc * VV; e += NT) {
+                const int r = e / VV, uv = e - r * VV;
+                const int u = uv / V, v = uv - u * V;
+                Dbuf[e] = fast_tanh(Pp[(r0 + r) * V + u] - Qp[(r0 + r) * V + v]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int ct = wave + it * NW;
+                if (ct < NTILE) {
+                    const int col = ct * 16 + j;
+                    const int colc = col < VV ? col : 0;
+                    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (k * 4 < rc) acc = mfma16(aw[k], Dbuf[(k * 4 + kq) * VV + colc], acc);
+                    if (col < VV) {
+                        const int u = col / V, v = col - u * V;
+                        const int off = transpose ? v * V + u : col;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int dst = (s * CT + kq * 4 + r) * VV + off;
+                            float tot = acc[r] + (r0 == 0 ? 0.f : Es[dst]);
+                            if (last) tot = alpha * (tot + b4r[r]) + Ar[it];
+                            Es[dst] = tot;
+                        }
                     }
                 }
             }
         }
     }
     __syncthreads();
+}
+
+// E tiles of channels c0..c0+15 from the tensor tamgcn_ctrgc_build_e wrote, (N, S, Cout, V*V): per subset the
+// 16 rows are one contiguous run, fetched with 16-byte loads in a single batch (the on-chip builder above costs
+// 14 % of the forward kernel at C = 64 and 45 % at C = 256, where 16 channel tiles repeat the same tanh work).
+template <class G, int ST>
+__device__ __forceinline__ void load_E(const float* __restrict__ Eg, int N_unused, int Cout, int n, int c0, float* Es, bool transpose) {
+    constexpr int V = G::V, VV = G::VV, NT = G::NT;
+    constexpr int PER = CT * VV / 4;                   // float4 per subset
+    constexpr int NL = (ST * PER + NT - 1) / NT;
+    (void)N_unused;
+    float4 t[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const int e = threadIdx.x + i * NT;
+        const int sidx = (e < ST * PER ? e : 0) / PER, r = (e < ST * PER ? e : 0) - sidx * PER;
+        t[i] = reinterpret_cast<const float4*>(Eg + (((long long)n * ST + sidx) * Cout + c0) * VV)[r];
+    }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const int e = threadIdx.x + i * NT;
+        if (e < ST * PER) {
+            if (!transpose) {
+                reinterpret_cast<float4*>(Es)[e] = t[i];          // same linear order: [s][c][uv]
+            } else {
+                const float vals[4] = {t[i].x, t[i].y, t[i].z, t[i].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int f = e * 4 + k;
+                    const int row = f / VV, uv = f - row * VV;   // row = s*16 + c
+                    const int u = uv / V, v = uv - u * V;
+                    Es[row * VV + v * V + u] = vals[k];
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
+// E for every channel of one (sample, subset) -- tamgcn_ctrgc_build_e.  D = tanh(p_u - q_v) is built once
+// in LDS and reused by all Cout/16 channel tiles; tiles leave through LDS as 16-byte coalesced rows.
+// ---------------------------------------------------------------------------
+struct EArgs {
+    int N, Cout, S, R;
+    const float* pq; const float* w4; const float* b4; const float* A; const float* alpha;
+    float* E;
+};
+
+template <int V>
+__global__ __launch_bounds__(512) void ctrgc_E_kernel(const EArgs a) {
+    constexpr int VV = V * V, NT = 512, NW = 8, NTILE = (VV + 15) / 16, NIT = (NTILE + NW - 1) / NW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Tt = smem;                         // [16][VV] finished tile
+    float* Ds = Tt + 16 * VV;                 // [R][VV]
+    float* PQ = Ds + a.R * VV;                // [p|q][R][V]
+    const int n = blockIdx.x / a.S, s = blockIdx.x - n * a.S;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kq = lane >> 4;
+    const long long NV = (long long)a.N * V;
+    const float alpha = a.alpha[0];
+    {
+        constexpr int MAXL = 4;
+        const int cnt = 2 * a.R * V;
+        for (int e0 = tid; e0 < cnt; e0 += MAXL * NT) {
+            float t[MAXL];
+#pragma unroll
+            for (int i = 0; i < MAXL; ++i) {
+                const int e = e0 + i * NT;
+                const int row = (e < cnt ? e : 0) / V, v = (e < cnt ? e : 0) - row * V;
+                t[i] = a.pq[((long long)s * 2 * a.R + row) * NV + (long long)n * V + v];
+            }
+#pragma unroll
+            for (int i = 0; i < MAXL; ++i) {
+                const int e = e0 + i * NT;
+                if (e < cnt) PQ[e] = t[i];
+            }
+        }
+    }
+    float Ar[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int col = (wave + it * NW) * 16 + j;
+        Ar[it] = col < VV ? a.A[s * VV + col] : 0.f;
+    }
+    __syncthreads();
+    for (int e = tid; e < a.R * VV; e += NT) {
+        const int r = e / VV, uv = e - r * VV;
+        const int u = uv / V, v = uv - u * V;
+        Ds[e] = fast_tanh(PQ[r * V + u] - PQ[(a.R + r) * V + v]);
+    }
+    float aw[8], b4r[4];
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            aw[k] = (k * 4 + kq < a.R) ? a.w4[((long long)s * a.Cout + c0 + j) * a.R + k * 4 + kq] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b4r[r] = a.b4[s * a.Cout + c0 + kq * 4 + r];
+    };
+    fetch(0);
+    __syncthreads();
+    float* Eg = a.E + ((long long)n * a.S + s) * a.Cout * VV;
+    for (int c0 = 0; c0 < a.Cout; c0 += 16) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int ct = wave + it * NW;
+            if (ct < NTILE) {
+                const int col = ct * 16 + j;
+                const int colc = col < VV ? col : 0;
+                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (k * 4 < a.R) acc = mfma16(aw[k], Ds[(k * 4 + kq) * VV + colc], acc);
+                if (col < VV) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Tt[(kq * 4 + r) * VV + col] = alpha * (acc[r] + b4r[r]) + Ar[it];
+                }
+            }
+        }
+        if (c0 + 16 < a.Cout) fetch(c0 + 16);           // in flight under the store pass
+        __syncthreads();
+        for (int e = tid; e < 16 * VV / 4; e += NT)
+            reinterpret_cast<float4*>(Eg + (long long)c0 * VV)[e] = reinterpret_cast<const float4*>(Tt)[e];
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -364,13 +538,18 @@ __global__ __launch_bounds__(G::NT) void ctrgc_fwd_kernel(const CtrgcArgs a, flo
     const int c = tid / (G::NTQ * 4), tq = (tid >> 2) % G::NTQ, uq = tid & 3;
     const int lrow = tid % (G::NTQ * 4);               // lane index inside the channel row (copy-out)
 
-    build_E<G>(a, n, c0, Es, X3, a.regionB, false);
+    TG_T(tt0);
+    if (a.E) load_E<G, ST>(a.E, a.N, a.Cout, n, c0, Es, false);
+    else build_E<G>(a, n, c0, Es, X3, a.regionB, false);
+    TG_T(tt1); TG_ACC(0, tt1 - tt0);
 
     float st1 = 0.f, st2 = 0.f;
     for (int t0 = 0; t0 < a.T; t0 += G::BT) {
         const int bt = min(G::BT, a.T - t0);
         const int ncols = bt * V;
+        TG_T(ta);
         x3_chunk<G, ST>(a, n, c0, t0, bt, X3);
+        TG_T(tb); TG_ACC(1, tb - ta);
         float z[TB][G::UB];
 #pragma unroll
         for (int tt = 0; tt < TB; ++tt)
@@ -392,7 +571,9 @@ __global__ __launch_bounds__(G::NT) void ctrgc_fwd_kernel(const CtrgcArgs a, flo
                 }
             }
         }
+        TG_T(tc); TG_ACC(2, tc - tb);
         __syncthreads();
+        TG_T(td); TG_ACC(3, td - tc);
         float* yrow = y + (((long long)n * a.Cout + c0 + c) * a.T + t0) * V;
         for (int p = lrow; p < ncols; p += G::NTQ * 4) {
             float v = Zs[c * G::NCOLS + p];
@@ -414,7 +595,9 @@ __global__ __launch_bounds__(G::NT) void ctrgc_fwd_kernel(const CtrgcArgs a, flo
             }
         }
         // next chunk's first barrier (inside x3_chunk) protects Zs / X3 reuse
+        TG_T(te); TG_ACC(4, te - td);
     }
+    TG_T(tt2); TG_ACC(8, tt2 - tt0); TG_ACC(9, 1);
     if (stats_part) {
         // reduce over the NTQ*4 threads of the channel row (16 or 32 consecutive lanes)
 #pragma unroll
@@ -442,7 +625,8 @@ __global__ __launch_bounds__(G::NT) void ctrgc_bwd_dx3_kernel(const CtrgcArgs a,
     const int c = tid / (G::NTQ * 4), tq = (tid >> 2) % G::NTQ, vq = tid & 3;
     const int lrow = tid % (G::NTQ * 4);
 
-    build_E<G>(a, n, c0, Es, X3, a.regionB, true);
+    if (a.E) load_E<G, ST>(a.E, a.N, a.Cout, n, c0, Es, true);
+    else build_E<G>(a, n, c0, Es, X3, a.regionB, true);
 
     float sb[ST];
 #pragma unroll
@@ -693,7 +877,7 @@ static bool plan_for(int S, CtrgcPlan* p) {
     int x3 = S * 16 * G::PX3;
     int region = stage > x3 ? stage : x3;
     region = (region + 3) & ~3;
-    if (region < 4 * G::VV) return false;               // E/D builders need >= 4 rel-channels of scratch
+    if (region < 4 * G::VV) return false;               // E/D builders need >= 4 rel-channels of scratch (+ p/q: fill_args)
     size_t lds = sizeof(float) * ((size_t)S * CT * G::VV + region + (size_t)CT * G::NCOLS);
     p->pitchB = pitch; p->regionB = region; p->lds = lds;
     return lds <= 160 * 1024;
@@ -712,12 +896,16 @@ static int fill_args(const tamgcn_ctrgc_desc* d, const CtrgcPlan& p, CtrgcArgs* 
     if (!(d->N > 0 && d->Cin > 0 && d->Cout > 0 && d->R > 0 && d->T > 0)) { tamgcn_set_error("%s: bad dims", who); return -1; }
     if (d->Cout % CT) { tamgcn_set_error("%s: Cout=%d must be a multiple of %d", who, d->Cout, CT); return -1; }
     if (d->R % 4) { tamgcn_set_error("%s: R=%d must be a multiple of 4", who, d->R); return -1; }
+    if (p.regionB - ((2 * d->R * d->V + 3) & ~3) < 4 * d->V * d->V) {
+        tamgcn_set_error("%s: R=%d too large for the E builder's LDS scratch (V=%d)", who, d->R, d->V); return -1;
+    }
     if (!(d->x.x1 && d->pq && d->w3 && d->b3 && d->w4 && d->b4 && d->A && d->alpha)) { tamgcn_set_error("%s: null pointer", who); return -1; }
     if (d->x.x2 || d->x.coef || d->x.act) { tamgcn_set_error("%s: x must be a plain tensor (no fused prologue)", who); return -1; }
     if (d->x.coff + d->Cin > d->x.ctot) { tamgcn_set_error("%s: x channel slice out of range", who); return -1; }
     a->N = d->N; a->Cin = d->Cin; a->Cout = d->Cout; a->S = d->S; a->R = d->R; a->T = d->T;
     a->x = d->x.x1; a->x_ctot = d->x.ctot; a->x_coff = d->x.coff;
     a->pq = d->pq; a->w3 = d->w3; a->b3 = d->b3; a->w4 = d->w4; a->b4 = d->b4; a->A = d->A; a->alpha = d->alpha;
+    a->E = d->E;
     a->nct = d->Cout / CT; a->pitchB = p.pitchB; a->regionB = p.regionB;
     return 0;
 }
@@ -755,6 +943,29 @@ extern "C" int tamgcn_ctrgc_lds_bytes(int S, int V, int R) {
     CtrgcPlan p;
     if (plan_ctrgc(S, V, &p)) return -1;
     return (int)p.lds;
+}
+
+extern "C" int tamgcn_ctrgc_build_e(const tamgcn_ctrgc_desc* d, float* E, void* stream) {
+    TG_CHECK(d && E && d->pq && d->w4 && d->b4 && d->A && d->alpha, "tamgcn_ctrgc_build_e: null pointer");
+    TG_CHECK(d->N > 0 && d->S > 0 && d->Cout > 0 && d->Cout % 16 == 0, "tamgcn_ctrgc_build_e: bad shape N=%d S=%d Cout=%d", d->N, d->S, d->Cout);
+    TG_CHECK(d->R >= 4 && d->R <= 32 && d->R % 4 == 0, "tamgcn_ctrgc_build_e: R=%d outside 4..32 (leave E null: tiles are then built on chip)", d->R);
+    TG_CHECK(d->V == 20 || d->V == 25, "tamgcn_ctrgc_build_e: unsupported V=%d (V in {20,25})", d->V);
+    EArgs a;
+    a.N = d->N; a.Cout = d->Cout; a.S = d->S; a.R = d->R;
+    a.pq = d->pq; a.w4 = d->w4; a.b4 = d->b4; a.A = d->A; a.alpha = d->alpha; a.E = E;
+    const size_t lds = sizeof(float) * ((size_t)(16 + d->R) * d->V * d->V + 2 * (size_t)d->R * d->V);
+    if (d->V == 20) {
+        static bool f = false;
+        allow_lds(ctrgc_E_kernel<20>, 160 * 1024, &f);
+        hipLaunchKernelGGL((ctrgc_E_kernel<20>), dim3(d->N * d->S), dim3(512), lds, (hipStream_t)stream, a);
+    } else {
+        static bool f = false;
+        allow_lds(ctrgc_E_kernel<25>, 160 * 1024, &f);
+        hipLaunchKernelGGL((ctrgc_E_kernel<25>), dim3(d->N * d->S), dim3(512), lds, (hipStream_t)stream, a);
+    }
+    tamgcn_note_kernel("ctrgc_E_kernel<%d>", d->V);
+    TG_LAUNCH_CHECK("tamgcn_ctrgc_build_e");
+    return 0;
 }
 
 extern "C" int tamgcn_ctrgc_fwd(const tamgcn_ctrgc_desc* d, float* y, float* stats_part, float* x3_out, void* stream) {

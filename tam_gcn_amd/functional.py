@@ -29,6 +29,9 @@ USE_SIDE_STREAMS = os.environ.get('TAMGCN_SIDE_STREAMS', '1') != '0'
 # keep x3 = conv3(x) from the forward for the backward (3 x one activation per block, ~3 GB at batch 256)
 # instead of recomputing the GEMM there; TAMGCN_KEEP_X3=0 trades the memory back for time
 KEEP_X3 = os.environ.get('TAMGCN_KEEP_X3', '1') != '0'
+# build E = alpha*(W4 tanh(p-q) + b4) + A once per layer into HBM (N*S*Cout*V*V floats) and let the CTRGC forward /
+# backward load their tiles, instead of every 16-channel tile rebuilding tanh(p-q) on chip; TAMGCN_GLOBAL_E=0 disables
+GLOBAL_E = os.environ.get('TAMGCN_GLOBAL_E', '1') != '0'
 
 
 class Fork:
@@ -124,8 +127,9 @@ def gcn_forward(x, P, training, save):
     xbar = ops.tmean(xs, Cin)                                             # (Cin, N, V)
     pq, _ = ops.conv(S(xbar.view(1, Cin, N, V)), K=Cin, w=P.W12, bias=P.B12, M=S_ * 2 * R)
     pq = pq.view(S_ * 2 * R, N, V)
+    E = ops.ctrgc_build_E(xs, pq, P.W3, P.B3, P.W4, P.B4, P.PA, P.alpha, Cin, Cout, S_, R) if (GLOBAL_E and R <= 32) else None
     y_pre, ypart, x3 = ops.ctrgc_fwd(xs, pq, P.W3, P.B3, P.W4, P.B4, P.PA, P.alpha, Cin, Cout, S_, R, stats=training,
-                                     keep_x3=save and KEEP_X3)
+                                     keep_x3=save and KEEP_X3, E=E)
     coef_y, save_y = _coef(Cout, x)
     P.bn.fwd(ypart, 0, count, training, coef_y, save_y, 0)
     fk.__exit__()                                      # join: d_pre and its coefficients are needed now
@@ -147,7 +151,7 @@ def gcn_forward(x, P, training, save):
     g = ops.gcn_tail_fwd(S(y_pre, coef=coef_y), S(o_pre, coef=coef_o), res)
     sv = None
     if save:
-        sv = dict(x=x, xbar=xbar, pq=pq, x3=x3, y_pre=y_pre, d_pre=d_pre, o_pre=o_pre, g=g, coef_y=coef_y, save_y=save_y,
+        sv = dict(x=x, xbar=xbar, pq=pq, x3=x3, E=E, y_pre=y_pre, d_pre=d_pre, o_pre=o_pre, g=g, coef_y=coef_y, save_y=save_y,
                   coef_d=coef_d, save_d=save_d, coef_o=coef_o, save_o=save_o, coef_diff=coef_diff,
                   training=training)
     return g, sv
@@ -194,7 +198,7 @@ def gcn_backward(P, sv, dg, need_dx=True, extra_dx=None):
         dxbar = None
         if need_dx:
             dxbar, _ = ops.conv(dpq4, K=S_ * 2 * R, w=P.W12, bias=None, M=Cin, wmode=1)    # (1, Cin, N, V)
-    dx3, G['B3'] = ops.ctrgc_bwd_dx3(*cargs)
+    dx3, G['B3'] = ops.ctrgc_bwd_dx3(*cargs, E=sv['E'])
     fk.refork()
     with fk.on(0):
         G['W3'] = ops.wgrad(S(dx3), xs, M=S_ * Cout, K=Cin)

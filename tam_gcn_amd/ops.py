@@ -158,19 +158,29 @@ def tmean(src, C_):
     return xbar
 
 
-def _ctrgc_desc(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R):
+def _ctrgc_desc(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, E=None):
     N, _, T, V = x.x1.shape
     d = CtrgcDesc()
     d.N, d.Cin, d.Cout, d.S, d.R, d.T, d.V = N, Cin, Cout, S, R, T, V
     d.x = x.c()
     d.pq, d.w3, d.b3, d.w4, d.b4, d.A, d.alpha = (_ptr(pq), _ptr(w3), _ptr(b3), _ptr(w4), _ptr(b4), _ptr(A), _ptr(alpha))
+    d.E = _ptr(E)
     return d
 
 
-def ctrgc_fwd(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, stats, keep_x3=False):
-    """Returns (y, stats_part, x3); x3 (N,S*Cout,T,V) only when keep_x3 (for the backward)."""
+def ctrgc_build_E(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R):
+    """E (N, S, Cout, V, V) for every channel, once per layer; hand it to ctrgc_fwd / ctrgc_bwd_dx3 (R <= 32)."""
     N, _, T, V = x.x1.shape
     d = _ctrgc_desc(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R)
+    E = empty(N, S, Cout, V, V, like=x.x1)
+    _lib.check(_lib_().tamgcn_ctrgc_build_e(C.byref(d), _ptr(E), _stream()), 'tamgcn_ctrgc_build_e')
+    return E
+
+
+def ctrgc_fwd(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, stats, keep_x3=False, E=None):
+    """Returns (y, stats_part, x3); x3 (N,S*Cout,T,V) only when keep_x3 (for the backward)."""
+    N, _, T, V = x.x1.shape
+    d = _ctrgc_desc(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, E)
     y = empty(N, Cout, T, V, like=x.x1)
     part = empty(2, Cout, N, like=x.x1) if stats else None
     x3 = empty(N, S * Cout, T, V, like=x.x1) if keep_x3 else None
@@ -178,10 +188,10 @@ def ctrgc_fwd(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, stats, keep_x3=F
     return y, part, x3
 
 
-def ctrgc_bwd_dx3(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy):
+def ctrgc_bwd_dx3(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy, E=None):
     """dx3 (N,S*Cout,T,V) = E^T . dy, and db3 [S*Cout]."""
     N, _, T, V = x.x1.shape
-    d = _ctrgc_desc(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R)
+    d = _ctrgc_desc(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, E)
     dyc = dy.c()
     dx3 = empty(N, S * Cout, T, V, like=x.x1)
     db3_part = empty(N, S * Cout, like=x.x1)

@@ -213,10 +213,20 @@ def test_ctrgc_fused_fwd_bwd(shape):
     close(x3k, x3r, 2e-4, 2e-4, 'x3 kept for the backward')
     yg0, _, none = ops.ctrgc_fwd(xs, pq, t(W3), t(B3), t(W4), t(B4), t(A), t(alpha), Cin, Cout, S_, R, stats=False)
     assert none is None and torch.equal(yg0, yg)
+    # E built once in HBM and loaded by the kernels vs E tiles built on chip
+    Eg = ops.ctrgc_build_E(xs, pq, t(W3), t(B3), t(W4), t(B4), t(A), t(alpha), Cin, Cout, S_, R)
+    Er = torch.stack([alpha * (torch.einsum('cr,nruv->ncuv', W4[s], torch.tanh(
+        pqr[(2 * s) * R:(2 * s + 1) * R].permute(1, 0, 2).unsqueeze(-1) - pqr[(2 * s + 1) * R:(2 * s + 2) * R].permute(1, 0, 2).unsqueeze(-2)))
+        + B4[s][None, :, None, None]) + A[s][None, None] for s in range(S_)], 1)
+    close(Eg, Er, 2e-4, 2e-5, 'E')
+    yg1, _, _ = ops.ctrgc_fwd(xs, pq, t(W3), t(B3), t(W4), t(B4), t(A), t(alpha), Cin, Cout, S_, R, stats=False, E=Eg)
+    close(yg1, yg, 1e-5, 1e-5, 'ctrgc fwd with E from HBM')
     close(part[0].sum(-1), y.sum((0, 2, 3)), 1e-3, 1e-2, 'stats')
     close(part[1].sum(-1), (y * y).sum((0, 2, 3)), 1e-3, 1e-2, 'stats2')
     dx3, db3, dA, dW4, db4, dal, dpq = ops.ctrgc_bwd(xs, pq, t(W3), t(B3), t(W4), t(B4), t(A), t(alpha),
                                                      Cin, Cout, S_, R, S(t(cot)))
+    dx3e, db3e = ops.ctrgc_bwd_dx3(xs, pq, t(W3), t(B3), t(W4), t(B4), t(A), t(alpha), Cin, Cout, S_, R, S(t(cot)), E=Eg)
+    close(dx3e, dx3, 1e-5, 1e-5 * float(dx3.abs().max()), 'dx3 with E from HBM')
     gpq, = torch.autograd.grad((y * cot).sum(), pqr, retain_graph=True)
     sc = lambda g: 2e-4 * (float(g.abs().max()) + 1e-3)
     # stored-x3 variant of the dE kernel against the recomputing one
