@@ -645,14 +645,20 @@ __global__ __launch_bounds__(G_NT, 2) void conv1x1_glds_kernel(const ConvArgs a,
         for (int c = 0; c < G_CWT; ++c) acc[mt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float lo = a.src.act == 1 ? 0.f : -__builtin_inff();
 
+    TG_T(tt0);
     __syncthreads();                                              // cf visible (no DMA in flight yet)
     const int nch = K / BK;
     issue(0);
     if (nch > 1) issue(1);
+    TG_T(tt1); TG_ACC(0, tt1 - tt0);
     for (int c = 0; c < nch; ++c) {
+        TG_T(ta);
         wait_vmcnt(c + 1 < nch ? nissue : 0);                     // this wave's pieces of chunk c have landed
+        TG_T(tb); TG_ACC(2, tb - ta);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // everyone's have; chunk c-1 fully consumed
+        TG_T(tc); TG_ACC(4, tc - tb);
         if (c + 2 < nch) issue(c + 2);
+        TG_T(td); TG_ACC(5, td - tc);
         const float* st = smem + (c % G_NST) * STG;
         const float* As = st + BK * G_PBMAX * NSRC + wm * 32 + j;
         const int k0 = c * BK;
@@ -679,7 +685,9 @@ __global__ __launch_bounds__(G_NT, 2) void conv1x1_glds_kernel(const ConvArgs a,
 #pragma unroll
                 for (int mt = 0; mt < G_MT; ++mt) acc[mt][cc] = mfma16(av[mt], bv[cc], acc[mt][cc]);
         }
+        TG_T(te); TG_ACC(6, te - td);
     }
+    TG_T(tg0);
 
     // ---- staged epilogue (two passes of 32 rows through the dead stage buffers)
     constexpr int PT = G_CWT * 64 + 4, RP = 32;
@@ -711,6 +719,7 @@ __global__ __launch_bounds__(G_NT, 2) void conv1x1_glds_kernel(const ConvArgs a,
             if (m < a.M) a.stats_part[((long long)stt * a.stats_ctot + a.stats_coff + m) * a.nparts + g] = Ss[stt * 4 * BM + row];
         }
     }
+    TG_T(tg1); TG_ACC(7, tg1 - tg0); TG_ACC(8, tg1 - tt0); TG_ACC(9, 1);
 }
 
 template <int NSRC, int BK>

@@ -1,7 +1,9 @@
 // HBM-bound element-wise epilogues of the CTR-GCN block and the per-channel
-// reductions their backward needs.  One workgroup streams one (n, c) row of
-// T*V contiguous floats (coalesced along t*V+v); per-channel partial sums go
-// to [stat][C][N] slabs (deterministic, finalised in fp64 by bn.hip).
+// reductions their backward needs.  A group of TPR lanes (16, 32 or 64: about five
+// 16-byte steps per lane, all loads independent) streams one (n, c) row of T*V
+// contiguous floats; a 256-thread workgroup carries 256/TPR rows and never
+// synchronises: row sums are wave shuffles.  Per-channel partial sums go to
+// [stat][C][N] slabs (deterministic, finalised in fp64 by bn.hip).
 // Reference: models/ctrgcn.py:117 (max-pool), :145-146, :256-261, :283.
 #include "common.h"
 
@@ -9,17 +11,23 @@ namespace {
 
 constexpr int EW_THREADS = 256;
 
-__device__ __forceinline__ void block_store_sums(const float* vals, int nst, float* part, int C, int N, int c, int n) {
-    __shared__ float red[8][4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// row geometry of a launch: lanes per row (power of two, 16..64) -> rows per workgroup
+struct RowGeo { int tpr, rows; };               // rows = N * C
+__device__ __forceinline__ bool row_coords(const RowGeo& g, int C, int& c, int& n, int& li) {
+    const int rpb = EW_THREADS / g.tpr;
+    const int row = blockIdx.x * rpb + threadIdx.x / g.tpr;
+    li = threadIdx.x & (g.tpr - 1);
+    const bool ok = row < g.rows;
+    const int r = ok ? row : 0;                    // idle lanes shadow row 0 (loads only) and take part in the shuffles
+    n = r / C; c = r - n * C;
+    return ok;
+}
+__device__ __forceinline__ void row_store_sums(const float* vals, int nst, float* part, int C, int N, int c, int n,
+                                               const RowGeo& g, int li, bool ok) {
     for (int s = 0; s < nst; ++s) {
-        float v = wave_sum64(vals[s]);
-        if (lane == 0) red[s][wave] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < nst) {
-        int s = threadIdx.x;
-        part[((long long)s * C + c) * N + n] = red[s][0] + red[s][1] + red[s][2] + red[s][3];
+        float v = vals[s];
+        for (int o = 1; o < g.tpr; o <<= 1) v += __shfl_xor(v, o);
+        if (li == 0 && ok) part[((long long)s * C + c) * N + n] = v;
     }
 }
 
@@ -53,16 +61,18 @@ __device__ __forceinline__ float4 row_val4(const RowSrc& r, int i4) {
 #define EW_VEC(L) (((L) & 3) == 0)
 
 // ---- unit_gcn tail -------------------------------------------------------
-__global__ __launch_bounds__(EW_THREADS) void gcn_tail_fwd_kernel(SrcDev y, SrcDev o, SrcDev res, int has_res,
+__global__ __launch_bounds__(EW_THREADS) void gcn_tail_fwd_kernel(RowGeo geo, SrcDev y, SrcDev o, SrcDev res, int has_res,
                                                                   int C, int L, float* g) {
-    const int c = blockIdx.x, n = blockIdx.y;
+    int c, n, li;
+    const bool rowok = row_coords(geo, C, c, n, li);
+    if (!rowok) L = 0;                     // idle lanes only take part in the shuffles
     const RowSrc ry = row_src(y, ((long long)n * y.ctot + y.coff + c) * L, y.coff + c);
     const RowSrc ro = row_src(o, ((long long)n * o.ctot + o.coff + c) * L, o.coff + c);
     RowSrc rr = ry;
     if (has_res) rr = row_src(res, ((long long)n * res.ctot + res.coff + c) * L, res.coff + c);
     float* gp = g + ((long long)n * C + c) * L;
     if (EW_VEC(L)) {
-        for (int i = threadIdx.x; i < (L >> 2); i += EW_THREADS) {
+        for (int i = li; i < (L >> 2); i += geo.tpr) {
             float4 a = row_val4(ry, i), b = row_val4(ro, i);
             float4 r = has_res ? row_val4(rr, i) : make_float4(0.f, 0.f, 0.f, 0.f);
             float4 v;
@@ -71,7 +81,7 @@ __global__ __launch_bounds__(EW_THREADS) void gcn_tail_fwd_kernel(SrcDev y, SrcD
             reinterpret_cast<float4*>(gp)[i] = v;
         }
     } else {
-        for (int i = threadIdx.x; i < L; i += EW_THREADS) {
+        for (int i = li; i < L; i += geo.tpr) {
             float v = row_val(ry, i) + tanhf(row_val(ro, i));
             if (has_res) v += row_val(rr, i);
             gp[i] = fmaxf(v, 0.f);
@@ -79,16 +89,18 @@ __global__ __launch_bounds__(EW_THREADS) void gcn_tail_fwd_kernel(SrcDev y, SrcD
     }
 }
 
-__global__ __launch_bounds__(EW_THREADS) void gcn_tail_bwd_kernel(const float* dg, const float* g, SrcDev o, const float* o_save,
+__global__ __launch_bounds__(EW_THREADS) void gcn_tail_bwd_kernel(RowGeo geo, const float* dg, const float* g, SrcDev o, const float* o_save,
                                                                   int C, int L, int N, float* dsum, float* doz, float* part) {
-    const int c = blockIdx.x, n = blockIdx.y;
+    int c, n, li;
+    const bool rowok = row_coords(geo, C, c, n, li);
+    if (!rowok) L = 0;                     // idle lanes only take part in the shuffles
     const long long b = ((long long)n * C + c) * L;
     const long long bo = ((long long)n * o.ctot + o.coff + c) * L;
     const RowSrc ro = row_src(o, bo, o.coff + c);
     float s[2] = {0.f, 0.f};
     const float mu = o_save[o.coff + c];
     if (EW_VEC(L)) {
-        for (int i = threadIdx.x; i < (L >> 2); i += EW_THREADS) {
+        for (int i = li; i < (L >> 2); i += geo.tpr) {
             float4 gg = reinterpret_cast<const float4*>(g + b)[i], dd = reinterpret_cast<const float4*>(dg + b)[i];
             float4 ob = row_val4(ro, i), op = reinterpret_cast<const float4*>(o.x1 + bo)[i];
             float4 d, z;
@@ -103,7 +115,7 @@ __global__ __launch_bounds__(EW_THREADS) void gcn_tail_bwd_kernel(const float* d
             s[1] = fmaf(z.x, op.x - mu, fmaf(z.y, op.y - mu, fmaf(z.z, op.z - mu, fmaf(z.w, op.w - mu, s[1]))));
         }
     } else {
-        for (int i = threadIdx.x; i < L; i += EW_THREADS) {
+        for (int i = li; i < L; i += geo.tpr) {
             float d = g[b + i] > 0.f ? dg[b + i] : 0.f;
             float off = tanhf(row_val(ro, i));
             float dz = d * (1.f - off * off);
@@ -113,18 +125,20 @@ __global__ __launch_bounds__(EW_THREADS) void gcn_tail_bwd_kernel(const float* d
             s[1] = fmaf(dz, o.x1[bo + i] - mu, s[1]);
         }
     }
-    block_store_sums(s, 2, part, C, N, c, n);
+    row_store_sums(s, 2, part, C, N, c, n, geo, li, rowok);
 }
 
-__global__ __launch_bounds__(EW_THREADS) void gcn_mid_bwd_kernel(const float* dsum, const float* ddiff, const float* y_pre, const float* y_save,
+__global__ __launch_bounds__(EW_THREADS) void gcn_mid_bwd_kernel(RowGeo geo, const float* dsum, const float* ddiff, const float* y_pre, const float* y_save,
                                                                  const float* r_pre, const float* r_save, int C, int L, int N,
                                                                  float* dyb, float* dres, float* part) {
-    const int c = blockIdx.x, n = blockIdx.y;
+    int c, n, li;
+    const bool rowok = row_coords(geo, C, c, n, li);
+    if (!rowok) L = 0;                     // idle lanes only take part in the shuffles
     const long long b = ((long long)n * C + c) * L;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     const float muy = y_save[c], mur = r_pre ? r_save[c] : 0.f;
     if (EW_VEC(L)) {
-        for (int i = threadIdx.x; i < (L >> 2); i += EW_THREADS) {
+        for (int i = li; i < (L >> 2); i += geo.tpr) {
             float4 d = reinterpret_cast<const float4*>(dsum + b)[i], dd = reinterpret_cast<const float4*>(ddiff + b)[i];
             float4 yp = reinterpret_cast<const float4*>(y_pre + b)[i];
             float4 rp = r_pre ? reinterpret_cast<const float4*>(r_pre + b)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -140,7 +154,7 @@ __global__ __launch_bounds__(EW_THREADS) void gcn_mid_bwd_kernel(const float* ds
             }
         }
     } else {
-        for (int i = threadIdx.x; i < L; i += EW_THREADS) {
+        for (int i = li; i < L; i += geo.tpr) {
             float d = dsum[b + i], dd = ddiff[b + i];
             float a = d - dd, r = d + dd;
             dyb[b + i] = a;
@@ -150,17 +164,19 @@ __global__ __launch_bounds__(EW_THREADS) void gcn_mid_bwd_kernel(const float* ds
             if (r_pre) { s[2] += r; s[3] = fmaf(r, r_pre[b + i] - mur, s[3]); }
         }
     }
-    block_store_sums(s, r_pre ? 4 : 2, part, C, N, c, n);
+    row_store_sums(s, r_pre ? 4 : 2, part, C, N, c, n, geo, li, rowok);
 }
 
 // ---- max-pool branch ------------------------------------------------------
-__global__ __launch_bounds__(EW_THREADS) void maxpool_fwd_kernel(SrcDev src, int C, int T_in, int V, int stride,
+__global__ __launch_bounds__(EW_THREADS) void maxpool_fwd_kernel(RowGeo geo, SrcDev src, int C, int T_in, int V, int stride,
                                                                  float* y, int yctot, int ycoff, int T_out, int N, float* part) {
-    const int c = blockIdx.x, n = blockIdx.y;
+    int c, n, li;
+    const bool rowok = row_coords(geo, C, c, n, li);
+    if (!rowok) T_out = 0;                     // idle lanes only take part in the shuffles
     const long long bs = ((long long)n * src.ctot + src.coff + c) * T_in * V;
     float* yp = y + ((long long)n * yctot + ycoff + c) * T_out * V;
     float s[2] = {0.f, 0.f};
-    for (int i = threadIdx.x; i < T_out * V; i += EW_THREADS) {
+    for (int i = li; i < T_out * V; i += geo.tpr) {
         int t = i / V, v = i - t * V;
         float best = -INFINITY;
         for (int k = -1; k <= 1; ++k) {
@@ -171,18 +187,20 @@ __global__ __launch_bounds__(EW_THREADS) void maxpool_fwd_kernel(SrcDev src, int
         s[0] += best;
         s[1] = fmaf(best, best, s[1]);
     }
-    if (part) block_store_sums(s, 2, part, yctot, N, ycoff + c, n);
+    if (part) row_store_sums(s, 2, part, yctot, N, ycoff + c, n, geo, li, rowok);
 }
 
-__global__ __launch_bounds__(EW_THREADS) void maxpool_bwd_kernel(SrcDev gy, SrcDev src, const float* src_save, int C, int T_in, int T_out, int V,
+__global__ __launch_bounds__(EW_THREADS) void maxpool_bwd_kernel(RowGeo geo, SrcDev gy, SrcDev src, const float* src_save, int C, int T_in, int T_out, int V,
                                                                  int stride, float* d, int dctot, int dcoff, int N, float* part) {
-    const int c = blockIdx.x, n = blockIdx.y;
+    int c, n, li;
+    const bool rowok = row_coords(geo, C, c, n, li);
+    if (!rowok) T_in = 0;                     // idle lanes only take part in the shuffles
     const long long bs = ((long long)n * src.ctot + src.coff + c) * T_in * V;
     const long long bg = ((long long)n * gy.ctot + gy.coff + c) * T_out * V;
     float* dp = d + ((long long)n * dctot + dcoff + c) * T_in * V;
     float s[2] = {0.f, 0.f};
     const float mu = src_save[src.coff + c];
-    for (int i = threadIdx.x; i < T_in * V; i += EW_THREADS) {
+    for (int i = li; i < T_in * V; i += geo.tpr) {
         int th = i / V, v = i - th * V;
         float x0 = src_value(src, bs + i, src.coff + c);
         float grad = 0.f;
@@ -206,26 +224,28 @@ __global__ __launch_bounds__(EW_THREADS) void maxpool_bwd_kernel(SrcDev gy, SrcD
         s[0] += grad;
         s[1] = fmaf(grad, src.x1[bs + i] - mu, s[1]);
     }
-    if (part) block_store_sums(s, 2, part, dctot, N, dcoff + c, n);
+    if (part) row_store_sums(s, 2, part, dctot, N, dcoff + c, n, geo, li, rowok);
 }
 
 // ---- residual add (+ReLU) -------------------------------------------------
-__global__ __launch_bounds__(EW_THREADS) void add_act_fwd_kernel(SrcDev a, SrcDev res, int has_res, int relu,
+__global__ __launch_bounds__(EW_THREADS) void add_act_fwd_kernel(RowGeo geo, SrcDev a, SrcDev res, int has_res, int relu,
                                                                  int C, int L, float* out) {
-    const int c = blockIdx.x, n = blockIdx.y;
+    int c, n, li;
+    const bool rowok = row_coords(geo, C, c, n, li);
+    if (!rowok) L = 0;                     // idle lanes only take part in the shuffles
     const RowSrc ra = row_src(a, ((long long)n * a.ctot + a.coff + c) * L, a.coff + c);
     RowSrc rr = ra;
     if (has_res) rr = row_src(res, ((long long)n * res.ctot + res.coff + c) * L, res.coff + c);
     float* op = out + ((long long)n * C + c) * L;
     if (EW_VEC(L)) {
-        for (int i = threadIdx.x; i < (L >> 2); i += EW_THREADS) {
+        for (int i = li; i < (L >> 2); i += geo.tpr) {
             float4 v = row_val4(ra, i);
             if (has_res) { float4 r = row_val4(rr, i); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
             if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             reinterpret_cast<float4*>(op)[i] = v;
         }
     } else {
-        for (int i = threadIdx.x; i < L; i += EW_THREADS) {
+        for (int i = li; i < L; i += geo.tpr) {
             float v = row_val(ra, i);
             if (has_res) v += row_val(rr, i);
             op[i] = relu ? fmaxf(v, 0.f) : v;
@@ -233,16 +253,18 @@ __global__ __launch_bounds__(EW_THREADS) void add_act_fwd_kernel(SrcDev a, SrcDe
     }
 }
 
-__global__ __launch_bounds__(EW_THREADS) void add_act_bwd_kernel(const float* dout, const float* out, int relu,
+__global__ __launch_bounds__(EW_THREADS) void add_act_bwd_kernel(RowGeo geo, const float* dout, const float* out, int relu,
                                                                  const float* a_pre, const float* a_save,
                                                                  const float* r_pre, const float* r_save,
                                                                  int C, int L, int N, float* dz, float* part) {
-    const int c = blockIdx.x, n = blockIdx.y;
+    int c, n, li;
+    const bool rowok = row_coords(geo, C, c, n, li);
+    if (!rowok) L = 0;                     // idle lanes only take part in the shuffles
     const long long b = ((long long)n * C + c) * L;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     const float mua = a_pre ? a_save[c] : 0.f, mur = r_pre ? r_save[c] : 0.f;
     if (EW_VEC(L)) {
-        for (int i = threadIdx.x; i < (L >> 2); i += EW_THREADS) {
+        for (int i = li; i < (L >> 2); i += geo.tpr) {
             float4 d = reinterpret_cast<const float4*>(dout + b)[i];
             if (relu) {
                 float4 o = reinterpret_cast<const float4*>(out + b)[i];
@@ -264,7 +286,7 @@ __global__ __launch_bounds__(EW_THREADS) void add_act_bwd_kernel(const float* do
             }
         }
     } else {
-        for (int i = threadIdx.x; i < L; i += EW_THREADS) {
+        for (int i = li; i < L; i += geo.tpr) {
             float d = dout[b + i];
             if (relu && !(out[b + i] > 0.f)) d = 0.f;
             if (dz) dz[b + i] = d;
@@ -273,14 +295,16 @@ __global__ __launch_bounds__(EW_THREADS) void add_act_bwd_kernel(const float* do
             if (r_pre) { s[2] += d; s[3] = fmaf(d, r_pre[b + i] - mur, s[3]); }
         }
     }
-    block_store_sums(s, r_pre ? 4 : 2, part, C, N, c, n);
+    row_store_sums(s, r_pre ? 4 : 2, part, C, N, c, n, geo, li, rowok);
 }
 
-__global__ __launch_bounds__(EW_THREADS) void apply_kernel(SrcDev src, int L, float* y, int yctot, int ycoff) {
-    const int c = blockIdx.x, n = blockIdx.y;
+__global__ __launch_bounds__(EW_THREADS) void apply_kernel(RowGeo geo, SrcDev src, int C, int L, float* y, int yctot, int ycoff) {
+    int c, n, li;
+    const bool rowok = row_coords(geo, C, c, n, li);
+    if (!rowok) L = 0;                     // idle lanes only take part in the shuffles
     const long long bs = ((long long)n * src.ctot + src.coff + c) * L;
     float* yp = y + ((long long)n * yctot + ycoff + c) * L;
-    for (int i = threadIdx.x; i < L; i += EW_THREADS) yp[i] = src_value(src, bs + i, src.coff + c);
+    for (int i = li; i < L; i += geo.tpr) yp[i] = src_value(src, bs + i, src.coff + c);
 }
 
 // xbar[c][n][v] = mean_t value(n,c,t,v)
@@ -295,7 +319,17 @@ __global__ __launch_bounds__(EW_THREADS) void tmean_kernel(SrcDev src, int N, in
     xbar[((long long)c * N + n) * V + v] = s / (float)T;
 }
 
-static bool grid_ok(int N, int C) { return N > 0 && C > 0 && N <= 65535; }
+static bool grid_ok(int N, int C) { return N > 0 && C > 0 && (long long)N * C < (1LL << 31); }
+
+// lanes per row: about five steps per lane (16-byte steps when the row length allows), 16..64
+static RowGeo row_geo(int N, int C, int L, bool vec_capable) {
+    const int steps = (vec_capable && (L & 3) == 0) ? L >> 2 : L;
+    int tpr = 16;
+    while (tpr < 64 && tpr * 5 < steps) tpr <<= 1;
+    RowGeo g; g.tpr = tpr; g.rows = N * C;
+    return g;
+}
+static dim3 row_grid(const RowGeo& g) { return dim3((unsigned)ceil_div(g.rows, EW_THREADS / g.tpr)); }
 
 }  // namespace
 
@@ -304,8 +338,9 @@ extern "C" int tamgcn_ew_nparts(int N, int C, int T, int V) { (void)C; (void)T; 
 extern "C" int tamgcn_gcn_tail_fwd(const tamgcn_src* y, const tamgcn_src* o, const tamgcn_src* res,
                                    int N, int C, int T, int V, float* g, void* stream) {
     TG_CHECK(y && o && g && y->x1 && o->x1 && grid_ok(N, C), "tamgcn_gcn_tail_fwd: bad args");
-    hipLaunchKernelGGL(gcn_tail_fwd_kernel, dim3(C, N), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                       make_src(*y), make_src(*o), res ? make_src(*res) : null_src(), res ? 1 : 0, C, T * V, g);
+    const RowGeo geo = row_geo(N, C, T * V, true);
+    hipLaunchKernelGGL(gcn_tail_fwd_kernel, row_grid(geo), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       geo, make_src(*y), make_src(*o), res ? make_src(*res) : null_src(), res ? 1 : 0, C, T * V, g);
     tamgcn_note_kernel("gcn_tail_fwd_kernel");
     TG_LAUNCH_CHECK("tamgcn_gcn_tail_fwd");
     return 0;
@@ -314,8 +349,9 @@ extern "C" int tamgcn_gcn_tail_fwd(const tamgcn_src* y, const tamgcn_src* o, con
 extern "C" int tamgcn_gcn_tail_bwd(const float* dg, const float* g, const tamgcn_src* o, const float* o_save,
                                    int N, int C, int T, int V, float* dsum, float* doz, float* part, void* stream) {
     TG_CHECK(dg && g && o && o->x1 && o_save && dsum && doz && part && grid_ok(N, C), "tamgcn_gcn_tail_bwd: bad args");
-    hipLaunchKernelGGL(gcn_tail_bwd_kernel, dim3(C, N), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                       dg, g, make_src(*o), o_save, C, T * V, N, dsum, doz, part);
+    const RowGeo geo = row_geo(N, C, T * V, true);
+    hipLaunchKernelGGL(gcn_tail_bwd_kernel, row_grid(geo), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       geo, dg, g, make_src(*o), o_save, C, T * V, N, dsum, doz, part);
     tamgcn_note_kernel("gcn_tail_bwd_kernel");
     TG_LAUNCH_CHECK("tamgcn_gcn_tail_bwd");
     return 0;
@@ -325,8 +361,9 @@ extern "C" int tamgcn_gcn_mid_bwd(const float* dsum, const float* ddiff, const f
                                   const float* r_pre, const float* r_save,
                                   int N, int C, int T, int V, float* dyb, float* dres, float* part, void* stream) {
     TG_CHECK(dsum && ddiff && y_pre && y_save && dyb && part && grid_ok(N, C) && (!r_pre || r_save), "tamgcn_gcn_mid_bwd: bad args");
-    hipLaunchKernelGGL(gcn_mid_bwd_kernel, dim3(C, N), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                       dsum, ddiff, y_pre, y_save, r_pre, r_save, C, T * V, N, dyb, dres, part);
+    const RowGeo geo = row_geo(N, C, T * V, true);
+    hipLaunchKernelGGL(gcn_mid_bwd_kernel, row_grid(geo), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       geo, dsum, ddiff, y_pre, y_save, r_pre, r_save, C, T * V, N, dyb, dres, part);
     tamgcn_note_kernel("gcn_mid_bwd_kernel");
     TG_LAUNCH_CHECK("tamgcn_gcn_mid_bwd");
     return 0;
@@ -336,8 +373,9 @@ extern "C" int tamgcn_maxpool_fwd(const tamgcn_src* src, int N, int C, int T_in,
                                   float* y, int yctot, int ycoff, int T_out, float* stats_part, void* stream) {
     TG_CHECK(src && src->x1 && y && grid_ok(N, C) && stride >= 1, "tamgcn_maxpool_fwd: bad args");
     TG_CHECK(T_out == (T_in + 2 - 3) / stride + 1, "tamgcn_maxpool_fwd: T_out=%d inconsistent with T_in=%d stride=%d", T_out, T_in, stride);
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(C, N), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                       make_src(*src), C, T_in, V, stride, y, yctot, ycoff, T_out, N, stats_part);
+    const RowGeo geo = row_geo(N, C, T_out * V, false);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, row_grid(geo), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       geo, make_src(*src), C, T_in, V, stride, y, yctot, ycoff, T_out, N, stats_part);
     tamgcn_note_kernel("maxpool_fwd_kernel");
     TG_LAUNCH_CHECK("tamgcn_maxpool_fwd");
     return 0;
@@ -346,8 +384,9 @@ extern "C" int tamgcn_maxpool_fwd(const tamgcn_src* src, int N, int C, int T_in,
 extern "C" int tamgcn_maxpool_bwd(const tamgcn_src* gy, const tamgcn_src* src, const float* src_save, int N, int C, int T_in, int T_out, int V,
                                   int stride, float* d, int dctot, int dcoff, float* part, void* stream) {
     TG_CHECK(gy && src && gy->x1 && src->x1 && src_save && d && grid_ok(N, C) && stride >= 1, "tamgcn_maxpool_bwd: bad args");
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(C, N), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                       make_src(*gy), make_src(*src), src_save, C, T_in, T_out, V, stride, d, dctot, dcoff, N, part);
+    const RowGeo geo = row_geo(N, C, T_in * V, false);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, row_grid(geo), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       geo, make_src(*gy), make_src(*src), src_save, C, T_in, T_out, V, stride, d, dctot, dcoff, N, part);
     tamgcn_note_kernel("maxpool_bwd_kernel");
     TG_LAUNCH_CHECK("tamgcn_maxpool_bwd");
     return 0;
@@ -356,8 +395,9 @@ extern "C" int tamgcn_maxpool_bwd(const tamgcn_src* gy, const tamgcn_src* src, c
 extern "C" int tamgcn_add_act_fwd(const tamgcn_src* a, const tamgcn_src* res, int relu,
                                   int N, int C, int T, int V, float* out, void* stream) {
     TG_CHECK(a && a->x1 && out && grid_ok(N, C), "tamgcn_add_act_fwd: bad args");
-    hipLaunchKernelGGL(add_act_fwd_kernel, dim3(C, N), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                       make_src(*a), res ? make_src(*res) : null_src(), res ? 1 : 0, relu, C, T * V, out);
+    const RowGeo geo = row_geo(N, C, T * V, true);
+    hipLaunchKernelGGL(add_act_fwd_kernel, row_grid(geo), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       geo, make_src(*a), res ? make_src(*res) : null_src(), res ? 1 : 0, relu, C, T * V, out);
     tamgcn_note_kernel("add_act_fwd_kernel");
     TG_LAUNCH_CHECK("tamgcn_add_act_fwd");
     return 0;
@@ -367,8 +407,9 @@ extern "C" int tamgcn_add_act_bwd(const float* dout, const float* out, int relu,
                                   const float* r_pre, const float* r_save,
                                   int N, int C, int T, int V, float* dz, float* part, void* stream) {
     TG_CHECK(dout && part && grid_ok(N, C) && (!relu || out) && (!a_pre || a_save) && (!r_pre || r_save), "tamgcn_add_act_bwd: bad args");
-    hipLaunchKernelGGL(add_act_bwd_kernel, dim3(C, N), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                       dout, out, relu, a_pre, a_save, r_pre, r_save, C, T * V, N, dz, part);
+    const RowGeo geo = row_geo(N, C, T * V, true);
+    hipLaunchKernelGGL(add_act_bwd_kernel, row_grid(geo), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       geo, dout, out, relu, a_pre, a_save, r_pre, r_save, C, T * V, N, dz, part);
     tamgcn_note_kernel("add_act_bwd_kernel");
     TG_LAUNCH_CHECK("tamgcn_add_act_bwd");
     return 0;
@@ -376,8 +417,9 @@ extern "C" int tamgcn_add_act_bwd(const float* dout, const float* out, int relu,
 
 extern "C" int tamgcn_apply(const tamgcn_src* src, int N, int C, int T, int V, float* y, int yctot, int ycoff, void* stream) {
     TG_CHECK(src && src->x1 && y && grid_ok(N, C), "tamgcn_apply: bad args");
-    hipLaunchKernelGGL(apply_kernel, dim3(C, N), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                       make_src(*src), T * V, y, yctot, ycoff);
+    const RowGeo geo = row_geo(N, C, T * V, false);
+    hipLaunchKernelGGL(apply_kernel, row_grid(geo), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       geo, make_src(*src), C, T * V, y, yctot, ycoff);
     tamgcn_note_kernel("apply_kernel");
     TG_LAUNCH_CHECK("tamgcn_apply");
     return 0;

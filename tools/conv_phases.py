@@ -18,8 +18,8 @@ lib.tamgcn_trace_read(buf, 1)
 runpy.run_path(os.path.join(ROOT, 'tools', 'kconv_only.py'), run_name='__main__')
 torch.cuda.synchronize()
 lib.tamgcn_trace_read(buf, 1)
-names = ['prologue(cf+first prefetch+sync)', 'barrier top of chunk', 'wait prefetched loads (vmcnt0)', 'stage A/B into LDS',
-         'barrier after stage', 'issue next prefetch', 'MFMA loop (issue)', 'epilogue', 'whole workgroup']
+names = ['prologue (cf, first loads)', 'barrier top of chunk (reg-staged kernel)', 'wait for the chunk\'s loads (vmcnt)', 'stage A/B into LDS (reg-staged kernel)',
+         'barrier', 'issue next loads', 'MFMA loop (issue)', 'epilogue', 'whole workgroup']
 nb = buf[9] or 1
 print(f'workgroups traced: {nb}; shader clocks per workgroup (wave 0):')
 for i, nm in enumerate(names):
