@@ -587,7 +587,7 @@ __global__ __launch_bounds__(G_NT, 2) void conv1x1_glds_kernel(const ConvArgs a,
     const int NI1 = (BK / 4) * NQ;                                // pieces per source and chunk
     int b_rel[MAXB], b_dst[MAXB];                                 // source offset (floats), LDS offset of the piece (floats)
     bool b_ok[MAXB], b_on[MAXB];
-    int nissue = NAI;
+    int nissue = 0;                                               // + the A pieces, below
 #pragma unroll
     for (int i = 0; i < MAXB; ++i) {
         const int id = wave + i * 8;
@@ -607,17 +607,42 @@ __global__ __launch_bounds__(G_NT, 2) void conv1x1_glds_kernel(const ConvArgs a,
     }
     const float* xb1 = a.src.x1 + ((long long)n * a.src.ctot + a.src.coff) * TV + (long long)t0 * V;
     const float* xb2 = NSRC == 2 ? a.src.x2 + ((long long)n * a.src.ctot + a.src.coff) * TV + (long long)t0 * V : nullptr;
-    const bool a_ok = m0 + lane < a.M;
-    const float* wbase = a.w + (long long)(m0 + lane) * a.ws_m + a.w_off;
+    // A (weight) pieces.  wmode 1 (w[k][m], data gradient): one dword piece per k row, lane = channel, coalesced.
+    // wmode 0 (w[m][k]): a row's BK taps are contiguous, so 64/BK*4.. lanes share a row: dwordx4 pieces of
+    // (1024 / (4*BK)) rows, image [m][BK]; the 16-byte quads of a row are XOR-swizzled on the SOURCE address
+    // (quad q of row m sits at q ^ f(m)) so the column reads below stay at most 2-way conflicted.
+    constexpr int RPP = 256 / BK;                                 // rows per 1 KB piece (wmode 0)
+    constexpr int NAP0 = G_BMT / RPP;                             // pieces per chunk (wmode 0): 4 (BK 16) or 2 (BK 8)
+    const bool wm0 = a.wmode == 0;
+    bool a_ok; const float* wbase; int a_dst0 = 0;
+    if (wm0) {
+        const int ml = lane / (BK / 4), q = lane - ml * (BK / 4);   // row inside the piece, physical quad
+        const int m = wave * RPP + ml;                              // row inside the tile (waves >= NAP0 idle)
+        const int f = BK == 16 ? (m >> 1) & 3 : (m >> 2) & 1;
+        a_ok = wave < NAP0 && m0 + m < a.M;
+        wbase = a.w + (long long)(m0 + (a_ok ? m : 0)) * a.ws_m + a.w_off + 4 * (q ^ f);
+        a_dst0 = wave * 256;
+    } else {
+        a_ok = m0 + lane < a.M;
+        wbase = a.w + (long long)(m0 + (a_ok ? lane : 0)) * a.ws_m + a.w_off;
+    }
+    const bool a_on = __ballot(a_ok) != 0ull;
+    nissue += wm0 ? (a_on ? 1 : 0) : NAI;
 
     auto issue = [&](int c) {
         float* st = smem + (c % G_NST) * STG;
         const int k0 = c * BK;
+        if (wm0) {
+            if (a_on) {
+                if (a_ok) __builtin_amdgcn_global_load_lds((tg_gptr)(wbase + k0), (tg_lptr)(st + BK * G_PBMAX * NSRC + a_dst0), 16, 0, 0);
+            }
+        } else {
 #pragma unroll
-        for (int i = 0; i < NAI; ++i) {
-            const int ka = wave * NAI + i;
-            if (a_ok) __builtin_amdgcn_global_load_lds((tg_gptr)(wbase + (long long)(k0 + ka) * a.ws_k),
-                                                       (tg_lptr)(st + BK * G_PBMAX * NSRC + ka * G_PA), 4, 0, 0);
+            for (int i = 0; i < NAI; ++i) {
+                const int ka = wave * NAI + i;
+                if (a_ok) __builtin_amdgcn_global_load_lds((tg_gptr)(wbase + (long long)(k0 + ka) * a.ws_k),
+                                                           (tg_lptr)(st + BK * G_PBMAX * NSRC + ka * G_PA), 4, 0, 0);
+            }
         }
 #pragma unroll
         for (int i = 0; i < MAXB; ++i) {
@@ -638,6 +663,15 @@ __global__ __launch_bounds__(G_NT, 2) void conv1x1_glds_kernel(const ConvArgs a,
         int sl = col - ((kq & 1) << 4);
         bslot[c] = sl < 0 ? sl + LB : sl;
     }
+    int aoff[BK / 4][G_MT];                                       // A fragment offsets inside a stage's A image
+#pragma unroll
+    for (int k4 = 0; k4 < BK / 4; ++k4)
+#pragma unroll
+        for (int mt = 0; mt < G_MT; ++mt) {
+            const int m = wm * 32 + mt * 16 + j;
+            const int f = BK == 16 ? (m >> 1) & 3 : (m >> 2) & 1;
+            aoff[k4][mt] = wm0 ? m * BK + 4 * (k4 ^ f) + kq : (k4 * 4 + kq) * G_PA + m;
+        }
     f32x4 acc[G_MT][G_CWT];
 #pragma unroll
     for (int mt = 0; mt < G_MT; ++mt)
@@ -660,14 +694,14 @@ __global__ __launch_bounds__(G_NT, 2) void conv1x1_glds_kernel(const ConvArgs a,
         if (c + 2 < nch) issue(c + 2);
         TG_T(td); TG_ACC(5, td - tc);
         const float* st = smem + (c % G_NST) * STG;
-        const float* As = st + BK * G_PBMAX * NSRC + wm * 32 + j;
+        const float* As = st + BK * G_PBMAX * NSRC;
         const int k0 = c * BK;
 #pragma unroll
         for (int k4 = 0; k4 < BK / 4; ++k4) {
             const int k = k4 * 4 + kq;
             float av[G_MT], bv[G_CWT];
 #pragma unroll
-            for (int mt = 0; mt < G_MT; ++mt) av[mt] = As[k * G_PA + mt * 16];
+            for (int mt = 0; mt < G_MT; ++mt) av[mt] = As[aoff[k4][mt]];
             const float c1 = cf[k0 + k], c0 = cf[2 * K + k0 + k];
             if constexpr (NSRC == 2) {
                 const float c2 = cf[K + k0 + k];
@@ -808,7 +842,7 @@ extern "C" int tamgcn_conv(const tamgcn_conv_desc* d, void* stream) {
     a.BT = p.BT; a.CW = p.CW; a.TIN = p.TIN; a.lstride = p.lstride; a.sB = p.sB; a.LB = p.LB; a.pitchB = p.pitchB;
     dim3 grid(p.ntt, ceil_div(d->M, BM), d->N);
     // 1x1 stride-1 convs whose rows are plain contiguous column ranges go to the LDS-DMA GEMM
-    const bool aligned16 = (((uintptr_t)d->src.x1 | (uintptr_t)(d->src.x2 ? d->src.x2 : d->src.x1)) & 15) == 0;
+    const bool aligned16 = (((uintptr_t)d->src.x1 | (uintptr_t)(d->src.x2 ? d->src.x2 : d->src.x1) | (uintptr_t)d->w) & 15) == 0;
     const bool glds = p.vec && d->KT == 1 && d->stride == 1 && d->up == 1 && d->ostride == 1 && d->pad == 0 &&
                       d->T_in == d->T_out && d->T_y == d->T_out && d->K % 16 == 0 && p.LB >= 64 && p.LB <= G_PBMAX &&
                       aligned16 && (long long)d->K * d->T_in * d->V < (1LL << 30);
@@ -937,7 +971,9 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(const WgradArgs a) {
     const int wr = wave >> 1, wc = wave & 1;
     const int k0 = blockIdx.x * BKW, m0 = blockIdx.y * BMW, split = blockIdx.z;
     const int V = a.V, V4 = (V + 3) >> 2;
-    const int n_begin = split * a.n_per, n_end = min(a.N, n_begin + a.n_per);
+    // a split owns a contiguous range of the (sample, frame chunk) sequence: splits may be finer than samples
+    const int cpt = (a.T_out + a.BT - 1) / a.BT;              // frame chunks per sample
+    const int c_begin = split * a.n_per, c_end = min(a.N * cpt, c_begin + a.n_per);
     const int mvalid = min(BMW, a.M - m0), kvalid = min(BKW, a.K - k0);
 
     for (int e = tid; e < BMW; e += NTHREADS) {
@@ -1035,9 +1071,10 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(const WgradArgs a) {
     };
 
     __syncthreads();                          // coefficient tables visible
-    if (n_begin < n_end) prefetch(n_begin, 0);
-    for (int n = n_begin; n < n_end; ++n) {
-        for (int t0 = 0; t0 < a.T_out; t0 += a.BT) {
+    if (c_begin < c_end) prefetch(c_begin / cpt, (c_begin % cpt) * a.BT);
+    for (int ci = c_begin; ci < c_end; ++ci) {
+        {
+            const int n = ci / cpt, t0 = (ci - n * cpt) * a.BT;
             const int bt = min(a.BT, a.T_out - t0);
             const int tin = (bt - 1) * a.stride + (KT - 1) * a.dil + 1;
             __syncthreads();
@@ -1051,9 +1088,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(const WgradArgs a) {
             }
             __syncthreads();
             if constexpr (PF) {               // next chunk's loads fly under this chunk's MFMAs
-                int nt0 = t0 + a.BT, nn = n;
-                if (nt0 >= a.T_out) { nt0 = 0; nn = n + 1; }
-                if (nn < n_end) prefetch(nn, nt0);
+                if (ci + 1 < c_end) prefetch((ci + 1) / cpt, ((ci + 1) % cpt) * a.BT);
             }
             for (int tl = 0; tl < bt; ++tl) {
 #pragma unroll 5
@@ -1317,7 +1352,7 @@ static int launch_wgrad(WgradArgs& a, hipStream_t s) {
         BT = BT / 2;
     }
     if (lds > 160 * 1024) { tamgcn_set_error("tamgcn_wgrad: tile does not fit LDS (V=%d)", V); return -1; }
-    a.n_per = ceil_div(a.N, a.nsplit);
+    a.n_per = ceil_div(a.N * ceil_div(a.T_out, a.BT), a.nsplit);          // frame chunks per split
     tamgcn_note_kernel("wgrad_kernel<%d, %d, %d, %s>", KT, WMT, WKT, vec ? "true" : "false");
     dim3 grid(ceil_div(a.K, BKW), ceil_div(a.M, BMW), a.nsplit);
     if (vec) {
@@ -1379,7 +1414,11 @@ static bool wgrad_glds_plan(const tamgcn_wgrad_desc* d, int* wmt, int* wkt) {
 extern "C" int tamgcn_wgrad_max_split(const tamgcn_wgrad_desc* d) {
     if (!d || d->N <= 0 || d->T_out <= 0 || d->V <= 0) return -1;
     int wmt, wkt;
-    if (!wgrad_glds_plan(d, &wmt, &wkt)) return d->N;
+    if (!wgrad_glds_plan(d, &wmt, &wkt)) {
+        // register-staged kernel: frame chunks hold at most 8 frames; keep >= 2 of those chunks per workgroup
+        const long long m = (long long)d->N * ((d->T_out + 7) / 8) / 2;
+        return (int)(m < d->N ? d->N : (m > 65535 ? 65535 : m));
+    }
     const long long chunks = (long long)d->N * (((long long)d->T_out * d->V) / W_PC);
     const long long m = chunks / 8;                      // at least 8 chunks of 32 per workgroup
     return (int)(m < d->N ? d->N : (m > 65535 ? 65535 : m));

@@ -190,19 +190,35 @@ __global__ __launch_bounds__(EW_THREADS) void maxpool_fwd_kernel(RowGeo geo, Src
     if (part) row_store_sums(s, 2, part, yctot, N, ycoff + c, n, geo, li, rowok);
 }
 
+// The window logic needs up to nine neighbouring activations per element; read straight from memory that is a
+// chain of dependent L2 round trips inside data-dependent control flow (3400 cycles per element measured).  With
+// LDS = 1 the row's activations (prologue applied) and its upstream gradients are staged in LDS first -- one
+// batch of coalesced loads -- and the window logic runs out of LDS.
+template <int LDS>
 __global__ __launch_bounds__(EW_THREADS) void maxpool_bwd_kernel(RowGeo geo, SrcDev gy, SrcDev src, const float* src_save, int C, int T_in, int T_out, int V,
                                                                  int stride, float* d, int dctot, int dcoff, int N, float* part) {
+    extern __shared__ __attribute__((aligned(16))) float ew_smem[];
     int c, n, li;
     const bool rowok = row_coords(geo, C, c, n, li);
-    if (!rowok) T_in = 0;                     // idle lanes only take part in the shuffles
-    const long long bs = ((long long)n * src.ctot + src.coff + c) * T_in * V;
-    const long long bg = ((long long)n * gy.ctot + gy.coff + c) * T_out * V;
-    float* dp = d + ((long long)n * dctot + dcoff + c) * T_in * V;
+    const int Lin = T_in * V, Lout = T_out * V;
+    const int lin = rowok ? Lin : 0;                   // idle lanes only take part in the barrier and the shuffles
+    const long long bs = ((long long)n * src.ctot + src.coff + c) * Lin;
+    const long long bg = ((long long)n * gy.ctot + gy.coff + c) * Lout;
+    float* dp = d + ((long long)n * dctot + dcoff + c) * Lin;
+    float* xs = ew_smem + (threadIdx.x / geo.tpr) * (Lin + Lout);
+    float* gs = xs + Lin;
+    if (LDS) {
+        for (int i = li; i < lin; i += geo.tpr) xs[i] = src_value(src, bs + i, src.coff + c);
+        for (int i = li; i < (rowok ? Lout : 0); i += geo.tpr) gs[i] = src_value(gy, bg + i, gy.coff + c);
+        __syncthreads();
+    }
+    auto xval = [&](int tt, int v) { return LDS ? xs[tt * V + v] : src_value(src, bs + (long long)tt * V + v, src.coff + c); };
+    auto gval = [&](int t, int v) { return LDS ? gs[t * V + v] : src_value(gy, bg + (long long)t * V + v, gy.coff + c); };
     float s[2] = {0.f, 0.f};
     const float mu = src_save[src.coff + c];
-    for (int i = li; i < T_in * V; i += geo.tpr) {
+    for (int i = li; i < lin; i += geo.tpr) {
         int th = i / V, v = i - th * V;
-        float x0 = src_value(src, bs + i, src.coff + c);
+        float x0 = xval(th, v);
         float grad = 0.f;
         if (x0 > 0.f) {
             // windows t with |t*stride - th| <= 1
@@ -214,10 +230,10 @@ __global__ __launch_bounds__(EW_THREADS) void maxpool_bwd_kernel(RowGeo geo, Src
                 for (int k = -1; k <= 1; ++k) {
                     int tt = t * stride + k;
                     if (tt < 0 || tt >= T_in) continue;
-                    float xv = (tt == th) ? x0 : src_value(src, bs + (long long)tt * V + v, src.coff + c);
+                    float xv = (tt == th) ? x0 : xval(tt, v);
                     if (xv > best) { best = xv; arg = tt; }
                 }
-                if (arg == th) grad += src_value(gy, bg + (long long)t * V + v, gy.coff + c);
+                if (arg == th) grad += gval(t, v);
             }
         }
         dp[i] = grad;
@@ -385,8 +401,13 @@ extern "C" int tamgcn_maxpool_bwd(const tamgcn_src* gy, const tamgcn_src* src, c
                                   int stride, float* d, int dctot, int dcoff, float* part, void* stream) {
     TG_CHECK(gy && src && gy->x1 && src->x1 && src_save && d && grid_ok(N, C) && stride >= 1, "tamgcn_maxpool_bwd: bad args");
     const RowGeo geo = row_geo(N, C, T_in * V, false);
-    hipLaunchKernelGGL(maxpool_bwd_kernel, row_grid(geo), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                       geo, make_src(*gy), make_src(*src), src_save, C, T_in, T_out, V, stride, d, dctot, dcoff, N, part);
+    const size_t lds = sizeof(float) * (size_t)(EW_THREADS / geo.tpr) * ((size_t)T_in * V + (size_t)T_out * V);
+    if (lds <= 64 * 1024)
+        hipLaunchKernelGGL(maxpool_bwd_kernel<1>, row_grid(geo), dim3(EW_THREADS), lds, (hipStream_t)stream,
+                           geo, make_src(*gy), make_src(*src), src_save, C, T_in, T_out, V, stride, d, dctot, dcoff, N, part);
+    else
+        hipLaunchKernelGGL(maxpool_bwd_kernel<0>, row_grid(geo), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                           geo, make_src(*gy), make_src(*src), src_save, C, T_in, T_out, V, stride, d, dctot, dcoff, N, part);
     tamgcn_note_kernel("maxpool_bwd_kernel");
     TG_LAUNCH_CHECK("tamgcn_maxpool_bwd");
     return 0;
