@@ -200,15 +200,16 @@ int tamgcn_ctrgc_bwd_de(const tamgcn_ctrgc_desc* d, const tamgcn_src* dy,
 
 /* The same chain when tamgcn_ctrgc_fwd kept x3 (x3_out), as two launches:
  *   _de_acc   dE (N, S, Cout, V, V) = sum_t dy(n,c,t,u) * x3[n, s*Cout+c, t, v]     (streaming, HBM-bound)
- *   _de_tail  one workgroup per (n, s): dA_part [N][S][V][V], dw4_part [N][S][Cout][R],
- *             db4_part [N][S][Cout], dalpha_part [N*S], dpq [S*2*R][N][V] (plain stores: every
- *             (n, s) owns its slice, nothing to zero).  R <= 32.
+ *   _de_tail  one workgroup per (n, s, channel group g of `groups`): dA_part [N*groups][S][V][V],
+ *             dw4_part [N][S][Cout][R], db4_part [N][S][Cout], dalpha_part [N*S*groups],
+ *             dpq [groups][S*2*R][N][V] (plain stores: every workgroup owns its slice, nothing to zero;
+ *             sum the slabs over `groups`).  R <= 32, Cout % (16*groups) == 0.
  * d->x and d->w3/b3 are not read by either. */
 int tamgcn_ctrgc_bwd_de_acc(const tamgcn_ctrgc_desc* d, const tamgcn_src* dy, const float* x3,
                             float* dE, void* stream);
 int tamgcn_ctrgc_bwd_de_tail(const tamgcn_ctrgc_desc* d, const float* dE,
                              float* dA_part, float* dw4_part, float* db4_part,
-                             float* dalpha_part, float* dpq, void* stream);
+                             float* dalpha_part, float* dpq, int groups, void* stream);
 
 /* ------------------------------------------------------------------------
  * Element-wise block epilogues and their backward reductions.

@@ -67,7 +67,7 @@ SIGNATURES = {
     'tamgcn_ctrgc_bwd_dx3': (_i, [C.POINTER(CtrgcDesc), _SP, _p, _p, _p]),
     'tamgcn_ctrgc_bwd_de': (_i, [C.POINTER(CtrgcDesc), _SP, _p, _p, _p, _p, _p, _p]),
     'tamgcn_ctrgc_bwd_de_acc': (_i, [C.POINTER(CtrgcDesc), _SP, _p, _p, _p]),
-    'tamgcn_ctrgc_bwd_de_tail': (_i, [C.POINTER(CtrgcDesc), _p, _p, _p, _p, _p, _p, _p]),
+    'tamgcn_ctrgc_bwd_de_tail': (_i, [C.POINTER(CtrgcDesc), _p, _p, _p, _p, _p, _p, _i, _p]),
     'tamgcn_ew_nparts': (_i, [_i, _i, _i, _i]),
     'tamgcn_gcn_tail_fwd': (_i, [_SP, _SP, _SP, _i, _i, _i, _i, _p, _p]),
     'tamgcn_gcn_tail_bwd': (_i, [_p, _p, _SP, _p, _i, _i, _i, _i, _p, _p, _p, _p]),

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(G::NT) void ctrgc_de_acc_kernel(int N, int Cout, in
 // kernel B: dE -> dA, db4, dW4, dalpha, dp, dq     (one workgroup per (n, s))
 // ---------------------------------------------------------------------------------------------
 struct TailArgs {
-    int N, Cout, S, R;
+    int N, Cout, S, R, G;        // G channel groups: a workgroup handles Cout/G channels of one (n, subset)
     const float* dE; const float* pq; const float* w4; const float* b4; const float* alpha;
     float* dA_part; float* dw4_part; float* db4_part; float* dalpha_part; float* dpq;
 };
@@ -210,7 +210,9 @@ __global__ __launch_bounds__(256) void ctrgc_de_tail_kernel(const TailArgs a) {
     float* Ds = smem;                        // [R][PD]    D, later dS in place
     float* DEs = Ds + a.R * PD;              // [16][PD]   dE chunk
     float* red = DEs + 16 * PD;              // [NW][16][RT*16]
-    const int n = blockIdx.x / a.S, s = blockIdx.x - n * a.S;
+    const int grp = blockIdx.x % a.G, ns = blockIdx.x / a.G;
+    const int n = ns / a.S, s = ns - n * a.S;
+    const int cg = a.Cout / a.G, cbeg = grp * cg, cend = cbeg + cg;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, mj = lane & 15, mkq = lane >> 4;
     const long long NV = (long long)a.N * V;
     const float alpha = a.alpha[0];
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(256) void ctrgc_de_tail_kernel(const TailArgs a) {
             pre[i] = e < 16 * VV / 4 ? g[e] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    load(0);
+    load(cbeg);
     {   // D[r][uv] = tanh(p[r][u] - q[r][v]); four (p, q) pairs in flight per thread
         const float* pb = a.pq + ((long long)(s * 2 + 0) * a.R) * NV + (long long)n * V;
         const float* qb = a.pq + ((long long)(s * 2 + 1) * a.R) * NV + (long long)n * V;
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(256) void ctrgc_de_tail_kernel(const TailArgs a) {
     for (int i = 0; i < NA; ++i) accA[i] = 0.f;
     float dalpha_acc = 0.f;
 
-    for (int c0 = 0; c0 < a.Cout; c0 += 16) {
+    for (int c0 = cbeg; c0 < cend; c0 += 16) {
         // W4^T fragment of this chunk: A[i = r][k = c]
         float aw[RT][4];
 #pragma unroll
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(256) void ctrgc_de_tail_kernel(const TailArgs a) {
             }
         }
         __syncthreads();
-        if (c0 + 16 < a.Cout) load(c0 + 16);
+        if (c0 + 16 < cend) load(c0 + 16);
         // dG[r][uv] += sum_c W4[c][r] dE[c][uv]
 #pragma unroll
         for (int j = 0; j < TPW; ++j) {
@@ -355,7 +357,7 @@ __global__ __launch_bounds__(256) void ctrgc_de_tail_kernel(const TailArgs a) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         int uv = tid + i * NT;
-        if (uv < VV) a.dA_part[((long long)n * a.S + s) * VV + uv] = accA[i];
+        if (uv < VV) a.dA_part[(((long long)n * a.G + grp) * a.S + s) * VV + uv] = accA[i];
     }
     __syncthreads();                         // every wave is done reading D
     // dS[r][uv] = alpha * dG * (1 - D^2), in place over D
@@ -390,12 +392,12 @@ __global__ __launch_bounds__(256) void ctrgc_de_tail_kernel(const TailArgs a) {
 #pragma unroll
             for (int u = 0; u < V; ++u) t -= Ds[r * PD + u * V + k];
         }
-        a.dpq[((long long)(s * 2 + which) * a.R + r) * NV + (long long)n * V + k] = t;
+        a.dpq[(((long long)grp * a.S * 2 + s * 2 + which) * a.R + r) * NV + (long long)n * V + k] = t;
     }
     dalpha_acc = wave_sum64(dalpha_acc);
     if (lane == 0) red_alpha[wave] = dalpha_acc;
     __syncthreads();
-    if (tid == 0) a.dalpha_part[n * a.S + s] = red_alpha[0] + red_alpha[1] + red_alpha[2] + red_alpha[3];
+    if (tid == 0) a.dalpha_part[(n * a.S + s) * a.G + grp] = red_alpha[0] + red_alpha[1] + red_alpha[2] + red_alpha[3];
 }
 
 template <typename K>
@@ -438,19 +440,20 @@ extern "C" int tamgcn_ctrgc_bwd_de_acc(const tamgcn_ctrgc_desc* d, const tamgcn_
         static bool flag = false;                                                                                      \
         const size_t lds = tail_lds<VV_>(d->R, RT_);                                                                   \
         allow_lds(ctrgc_de_tail_kernel<VV_, RT_>, tail_lds<VV_>(32, 2), &flag);                                        \
-        hipLaunchKernelGGL((ctrgc_de_tail_kernel<VV_, RT_>), dim3(d->N * d->S), dim3(256), lds, (hipStream_t)stream, a); \
+        hipLaunchKernelGGL((ctrgc_de_tail_kernel<VV_, RT_>), dim3(d->N * d->S * groups), dim3(256), lds, (hipStream_t)stream, a); \
         tamgcn_note_kernel("ctrgc_de_tail_kernel<%d, %d>", VV_, RT_);                                                  \
         launched = true;                                                                                               \
     }
 
 extern "C" int tamgcn_ctrgc_bwd_de_tail(const tamgcn_ctrgc_desc* d, const float* dE, float* dA_part, float* dw4_part, float* db4_part,
-                                        float* dalpha_part, float* dpq, void* stream) {
+                                        float* dalpha_part, float* dpq, int groups, void* stream) {
     TG_CHECK(d && dE && dA_part && dw4_part && db4_part && dalpha_part && dpq, "tamgcn_ctrgc_bwd_de_tail: null pointer");
     TG_CHECK(d->pq && d->w4 && d->b4 && d->alpha, "tamgcn_ctrgc_bwd_de_tail: null parameter pointer");
     TG_CHECK(d->N > 0 && d->S > 0 && d->Cout > 0 && d->Cout % 16 == 0, "tamgcn_ctrgc_bwd_de_tail: bad shape N=%d S=%d Cout=%d", d->N, d->S, d->Cout);
     TG_CHECK(d->R >= 1 && d->R <= 32, "tamgcn_ctrgc_bwd_de_tail: R=%d outside 1..32 (use tamgcn_ctrgc_bwd_de)", d->R);
     TailArgs a;
-    a.N = d->N; a.Cout = d->Cout; a.S = d->S; a.R = d->R;
+    TG_CHECK(groups >= 1 && d->Cout % (16 * groups) == 0, "tamgcn_ctrgc_bwd_de_tail: groups=%d must divide Cout/16=%d", groups, d->Cout / 16);
+    a.N = d->N; a.Cout = d->Cout; a.S = d->S; a.R = d->R; a.G = groups;
     a.dE = dE; a.pq = d->pq; a.w4 = d->w4; a.b4 = d->b4; a.alpha = d->alpha;
     a.dA_part = dA_part; a.dw4_part = dw4_part; a.db4_part = db4_part; a.dalpha_part = dalpha_part; a.dpq = dpq;
     const int rt = d->R <= 16 ? 1 : 2;

@@ -2,6 +2,7 @@
 output allocation through torch's caching allocator, the current HIP stream.
 No arithmetic happens here."""
 import ctypes as C
+import os
 
 import torch
 
@@ -91,6 +92,9 @@ def conv(src, K, w, bias, M, KT=1, dil=1, stride=1, pad=0, wmode=0, up=1,
     return y, part
 
 
+WGRAD_BLOCKS = int(os.environ.get('TAMGCN_WGRAD_BLOCKS', '512'))    # workgroups a weight gradient aims at (tiles x splits)
+
+
 def wgrad(gy, src, M, K, KT=1, dil=1, stride=1, pad=0):
     """Returns dW (M, K, KT, 1)."""
     N, _, T_out, V = gy.x1.shape
@@ -108,7 +112,7 @@ def wgrad(gy, src, M, K, KT=1, dil=1, stride=1, pad=0):
     d.N, d.M, d.K, d.T_in, d.T_out, d.V = N, M, K, T_in, T_out, V
     d.KT, d.dil, d.stride, d.pad = KT, dil, stride, pad
     lib = _lib_()
-    nsplit = max(1, min(lib.tamgcn_wgrad_max_split(C.byref(d)), (1024 + tiles - 1) // tiles))
+    nsplit = max(1, min(lib.tamgcn_wgrad_max_split(C.byref(d)), (WGRAD_BLOCKS + tiles - 1) // tiles))
     part = empty(nsplit, M, K, KT, like=gy.x1)
     d.part, d.nsplit = _ptr(part), nsplit
     _lib.check(lib.tamgcn_wgrad(C.byref(d), _stream()), 'tamgcn_wgrad')
@@ -213,15 +217,19 @@ def ctrgc_bwd_de(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy, x3=None):
         dE = empty(N, S, Cout, V, V, like=like)
         _lib.check(_lib_().tamgcn_ctrgc_bwd_de_acc(C.byref(d), C.byref(dyc), _ptr(x3), _ptr(dE), _stream()),
                    'tamgcn_ctrgc_bwd_de_acc')
-        dA_part = empty(N, S, V, V, like=like)
+        G = max(1, min(4, Cout // 64))                 # channel groups per (n, subset): parallelism for wide layers
+        while Cout % (16 * G):
+            G -= 1
+        dA_part = empty(N * G, S, V, V, like=like)
         dw4_part = empty(N, S, Cout, R, like=like)
         db4_part = empty(N, S, Cout, like=like)
-        dal_part = empty(N * S, 1, like=like)
-        dpq = empty(S * 2 * R, N, V, like=like)
+        dal_part = empty(N * S * G, 1, like=like)
+        dpq = empty(G, S * 2 * R, N, V, like=like)
         _lib.check(_lib_().tamgcn_ctrgc_bwd_de_tail(C.byref(d), _ptr(dE), _ptr(dA_part), _ptr(dw4_part), _ptr(db4_part),
-                                                    _ptr(dal_part), _ptr(dpq), _stream()), 'tamgcn_ctrgc_bwd_de_tail')
-        return (reduce_sum(dA_part, N), reduce_sum(dw4_part, N), reduce_sum(db4_part, N),
-                reduce_sum(dal_part, N * S), dpq)
+                                                    _ptr(dal_part), _ptr(dpq), G, _stream()), 'tamgcn_ctrgc_bwd_de_tail')
+        dpq = dpq[0] if G == 1 else reduce_sum(dpq, G)
+        return (reduce_sum(dA_part, N * G), reduce_sum(dw4_part, N), reduce_sum(db4_part, N),
+                reduce_sum(dal_part, N * S * G), dpq)
     nct = Cout // 16
     dA_part = empty(N * nct, S, V, V, like=like)
     dw4_part = empty(N, S, Cout, R, like=like)
