@@ -13,6 +13,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------
 void tamgcn_set_error(const char* fmt, ...);
 void tamgcn_note_kernel(const char* fmt, ...);   // symbol of the kernel the last ABI call launched (per thread)
+int tamgcn_split_mode(void);                     // TAMGCN_SPLIT_BF16: 0 = exact fp32-input MFMA everywhere, 1 (default) / 2 = split-fp32 on the bf16 matrix cores in the DMA GEMMs
 
 #define TG_CHECK(cond, ...)                         \
     do {                                            \
@@ -86,6 +87,39 @@ __device__ __forceinline__ float wave_sum64(float v) {
 // D[row = 4*(lane>>4) + reg][col = lane&15]   (cdna_hip_programming.md §3)
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------
+// split-fp32 operands for the bf16 matrix cores: x = hi + lo with hi = bf16(x) (RNE), lo = bf16(x - hi);
+// a.b ~= ah.bh + ah.bl + al.bh drops only al.bl and lo's rounding: ~2^-17 relative per product (4.5e-6 measured on
+// the layer GEMMs, tools/split_accuracy.py), at three v_mfma_f32_16x16x32_bf16 (K = 32, 16 cycles each) instead of
+// eight v_mfma_f32_16x16x4_f32 (32 cycles each): the fp32-input MFMA runs at 1/16 of the bf16 rate.  (The legacy
+// K = 16 bf16 form takes 32 cycles: measured, no faster than 1.37x.)  Fragment layout: lane (i = lane & 15,
+// kq = lane >> 4) supplies eight contraction indices; which eight is free as long as both operands agree.
+// The split costs 12 VALU per four elements, which is what bounds these loops.
+// ---------------------------------------------------------------------------
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+// eight fp32 values (two 16-byte fragments) -> hi and lo bf16x8 operands
+__device__ __forceinline__ void split_bf16x8(const f32x4& v0, const f32x4& v1, bf16x8_t& hi, bf16x8_t& lo) {
+    u32x4_t h, l;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        f32x2_t x = {p < 2 ? v0[2 * p] : v1[2 * p - 4], p < 2 ? v0[2 * p + 1] : v1[2 * p - 3]};
+        h[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2_t));          // v_cvt_pk_bf16_f32
+        f32x2_t r = {x[0] - __uint_as_float(h[p] << 16), x[1] - __uint_as_float(h[p] & 0xffff0000u)};
+        l[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
+    }
+    hi = __builtin_bit_cast(bf16x8_t, h);
+    lo = __builtin_bit_cast(bf16x8_t, l);
+}
+__device__ __forceinline__ f32x4 mfma_split(const bf16x8_t& ah, const bf16x8_t& al, const bf16x8_t& bh, const bf16x8_t& bl, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
 }
 
 // tanh(x) = 1 - 2/(exp(2x)+1): absolute error ~1e-7 (D is O(1) and enters E linearly)

@@ -1150,7 +1150,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(const WgradArgs a) {
 // ===========================================================================
 constexpr int W_PC = 32, W_NST = 3, W_NT = 512;
 
-template <int WMT, int WKT, int NY, int NX>
+template <int WMT, int WKT, int NY, int NX, bool SPL, int NST>
 __global__ __launch_bounds__(W_NT, 2) void wgrad_glds_kernel(const WgradArgs a, int ntk, int ntm) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int BMW = 2 * WMT * 16, BKW = 4 * WKT * 16;
@@ -1199,7 +1199,7 @@ __global__ __launch_bounds__(W_NT, 2) void wgrad_glds_kernel(const WgradArgs a, 
     }
     const long long ystep = (long long)a.gy.ctot * cs, xstep = (long long)a.src.ctot * cs;
     auto issue = [&](int c) {
-        float* st = smem + (c % W_NST) * STG;
+        float* st = smem + (c % NST) * STG;
         const int gc = c_begin + c, nn = gc / cps, pc = gc - nn * cps;
         const long long oy = (long long)nn * ystep + (long long)pc * W_PC;
         const long long ox = (long long)nn * xstep + (long long)pc * W_PC;
@@ -1233,6 +1233,7 @@ __global__ __launch_bounds__(W_NT, 2) void wgrad_glds_kernel(const WgradArgs a, 
         cx0[y] = ok ? a.src.coef[2 * a.src.ctot + ch] : 0.f;
     }
     const float loy = a.gy.act == 1 ? 0.f : -__builtin_inff(), lox = a.src.act == 1 ? 0.f : -__builtin_inff();
+    const bool yplain = !a.gy.coef && a.gy.act != 1, xplain = !a.src.coef && a.src.act != 1;   // plain tensors skip the prologue
 
     f32x4 acc[WMT][WKT];
 #pragma unroll
@@ -1244,17 +1245,19 @@ __global__ __launch_bounds__(W_NT, 2) void wgrad_glds_kernel(const WgradArgs a, 
     const int yoff = ((wr * WMT) * 16 + j) * W_PC, xoff = (RY + (wc * WKT) * 16 + j) * W_PC;
     const int sl0 = ((kq) ^ (j & 7)) * 4, sl1 = ((4 + kq) ^ (j & 7)) * 4;
 
+    // NST = 3: two chunks in flight; NST = 2 (tiles whose two-stage ring lets a second workgroup share the CU):
+    // one chunk in flight per workgroup, the neighbour covers the wait
     if (nch > 0) issue(0);
-    if (nch > 1) issue(1);
+    if (NST == 3 && nch > 1) issue(1);
     for (int c = 0; c < nch; ++c) {
-        wait_vmcnt(c + 1 < nch ? nissue : 0);
+        wait_vmcnt((NST == 3 && c + 1 < nch) ? nissue : 0);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (c + 2 < nch) issue(c + 2);
-        const float* st = smem + (c % W_NST) * STG;
+        if (c + NST - 1 < nch) issue(c + NST - 1);
+        const float* st = smem + (c % NST) * STG;
+        f32x4 av[2][WMT], bv[2][WKT];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int sl = b ? sl1 : sl0;
-            f32x4 av[WMT], bv[WKT];
 #pragma unroll
             for (int x = 0; x < WMT; ++x) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(st + yoff + x * 16 * W_PC + sl);
@@ -1262,11 +1265,11 @@ __global__ __launch_bounds__(W_NT, 2) void wgrad_glds_kernel(const WgradArgs a, 
                     f32x4 v2 = *reinterpret_cast<const f32x4*>(st + BMW * W_PC + yoff + x * 16 * W_PC + sl);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(cy1[x], v[e], fmaf(cy2[x], v2[e], cy0[x])), loy);
-                } else {
+                } else if (!yplain) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(cy1[x], v[e], cy0[x]), loy);
                 }
-                av[x] = v;
+                av[b][x] = v;
             }
 #pragma unroll
             for (int y = 0; y < WKT; ++y) {
@@ -1275,18 +1278,32 @@ __global__ __launch_bounds__(W_NT, 2) void wgrad_glds_kernel(const WgradArgs a, 
                     f32x4 v2 = *reinterpret_cast<const f32x4*>(st + BKW * W_PC + xoff + y * 16 * W_PC + sl);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(cx1[y], v[e], fmaf(cx2[y], v2[e], cx0[y])), lox);
-                } else {
+                } else if (!xplain) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(cx1[y], v[e], cx0[y]), lox);
                 }
-                bv[y] = v;
+                bv[b][y] = v;
             }
+        }
+        if constexpr (SPL) {                // the lane's eight contraction indices of this chunk = one K = 32 fragment
+            bf16x8_t ah[WMT], al[WMT], bh[WKT], bl[WKT];
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+            for (int x = 0; x < WMT; ++x) split_bf16x8(av[0][x], av[1][x], ah[x], al[x]);
 #pragma unroll
-                for (int y = 0; y < WKT; ++y)
+            for (int y = 0; y < WKT; ++y) split_bf16x8(bv[0][y], bv[1][y], bh[y], bl[y]);
 #pragma unroll
-                    for (int x = 0; x < WMT; ++x) acc[x][y] = mfma16(av[x][e], bv[y][e], acc[x][y]);
+            for (int y = 0; y < WKT; ++y)
+#pragma unroll
+                for (int x = 0; x < WMT; ++x) acc[x][y] = mfma_split(ah[x], al[x], bh[y], bl[y], acc[x][y]);
+        } else {
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int y = 0; y < WKT; ++y)
+#pragma unroll
+                        for (int x = 0; x < WMT; ++x) acc[x][y] = mfma16(av[b][x][e], bv[b][y][e], acc[x][y]);
         }
     }
     float* out = a.part + (long long)split * a.M * a.K;
@@ -1302,26 +1319,37 @@ __global__ __launch_bounds__(W_NT, 2) void wgrad_glds_kernel(const WgradArgs a, 
             }
 }
 
-template <int WMT, int WKT, int NY, int NX>
+template <int WMT, int WKT, int NY, int NX, bool SPL>
 static int launch_wgrad_glds(WgradArgs& a, hipStream_t s) {
     constexpr int BMW = 2 * WMT * 16, BKW = 4 * WKT * 16;
-    const size_t lds = sizeof(float) * (size_t)W_NST * (BMW * NY + BKW * NX) * W_PC;
+    constexpr size_t STAGE = sizeof(float) * (size_t)(BMW * NY + BKW * NX) * W_PC;
+    // a third stage only where it does not cost the second workgroup per CU
+    constexpr int NST = (2 * STAGE <= 80 * 1024 && 3 * STAGE > 80 * 1024) ? 2 : W_NST;
+    const size_t lds = NST * STAGE;
     static bool flag = false;
-    if (!flag) { (void)hipFuncSetAttribute((const void*)wgrad_glds_kernel<WMT, WKT, NY, NX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); flag = true; }
+    if (!flag) { (void)hipFuncSetAttribute((const void*)wgrad_glds_kernel<WMT, WKT, NY, NX, SPL, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); flag = true; }
     a.n_per = ceil_div(a.N * (int)(((long long)a.T_out * a.V) / W_PC), a.nsplit);   // chunks per split
     const int ntk = ceil_div(a.K, BKW), ntm = ceil_div(a.M, BMW);
-    hipLaunchKernelGGL((wgrad_glds_kernel<WMT, WKT, NY, NX>), dim3((unsigned)(ntk * ntm * a.nsplit)), dim3(W_NT), lds, s, a, ntk, ntm);
-    tamgcn_note_kernel("wgrad_glds_kernel<%d, %d, %d, %d>", WMT, WKT, NY, NX);
+    hipLaunchKernelGGL((wgrad_glds_kernel<WMT, WKT, NY, NX, SPL, NST>), dim3((unsigned)(ntk * ntm * a.nsplit)), dim3(W_NT), lds, s, a, ntk, ntm);
+    tamgcn_note_kernel("wgrad_glds_kernel<%d, %d, %d, %d, %s, %d>", WMT, WKT, NY, NX, SPL ? "split" : "f32", NST);
     return 0;
 }
 
+template <int WMT, int WKT, bool SPL>
+static int launch_wgrad_glds_spl(WgradArgs& a, hipStream_t s) {
+    const bool y2 = a.gy.x2 != nullptr, x2 = a.src.x2 != nullptr;
+    if (y2 && x2) return launch_wgrad_glds<WMT, WKT, 2, 2, SPL>(a, s);
+    if (y2) return launch_wgrad_glds<WMT, WKT, 2, 1, SPL>(a, s);
+    if (x2) return launch_wgrad_glds<WMT, WKT, 1, 2, SPL>(a, s);
+    return launch_wgrad_glds<WMT, WKT, 1, 1, SPL>(a, s);
+}
+
+// split-fp32 MFMA (TAMGCN_SPLIT_BF16 >= 1, the default) or the exact fp32-input MFMA (0)
 template <int WMT, int WKT>
 static int launch_wgrad_glds_src(WgradArgs& a, hipStream_t s) {
-    const bool y2 = a.gy.x2 != nullptr, x2 = a.src.x2 != nullptr;
-    if (y2 && x2) return launch_wgrad_glds<WMT, WKT, 2, 2>(a, s);
-    if (y2) return launch_wgrad_glds<WMT, WKT, 2, 1>(a, s);
-    if (x2) return launch_wgrad_glds<WMT, WKT, 1, 2>(a, s);
-    return launch_wgrad_glds<WMT, WKT, 1, 1>(a, s);
+    const int mode = tamgcn_split_mode();
+    const bool spl = mode >= 1;            // measured faster at every layer shape, HBM-bound ones included (fewer MFMA cycles per byte)
+    return spl ? launch_wgrad_glds_spl<WMT, WKT, true>(a, s) : launch_wgrad_glds_spl<WMT, WKT, false>(a, s);
 }
 
 static inline int even_pitch(int n) {      // smallest p >= n with p == 2 (mod 4): conflict-free column reads, 8-byte rows

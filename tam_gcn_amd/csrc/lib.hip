@@ -1,5 +1,6 @@
 // Library-level entry points: version and per-thread error text.
 #include "common.h"
+#include <stdlib.h>
 #include <string.h>
 
 static thread_local char g_err[512] = "";
@@ -23,3 +24,14 @@ void tamgcn_note_kernel(const char* fmt, ...) {
 extern "C" const char* tamgcn_last_kernel(void) { return g_kernel; }
 extern "C" int tamgcn_version(void) { return TAMGCN_VERSION; }
 extern "C" const char* tamgcn_last_error(void) { return g_err; }
+
+// Split-fp32 (3 x bf16 MFMA) policy for the GEMM kernels, read once from the environment.
+int tamgcn_split_mode(void) {
+    static int mode = -1;
+    if (mode < 0) {
+        const char* e = getenv("TAMGCN_SPLIT_BF16");
+        mode = e ? atoi(e) : 1;
+        if (mode < 0 || mode > 2) mode = 1;
+    }
+    return mode;
+}
