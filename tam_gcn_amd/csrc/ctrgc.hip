@@ -319,7 +319,7 @@ __global__ __launch_bounds__(512) void ctrgc_E_kernel(const EArgs a) {
 // x3 tile for frames [t0, t0+bt): X3[(s*16+c)*PX3 + tl*V + v] = (W3_s x)[c0+c] + b3
 // The staging buffers alias the X3 tile (they are dead before the tile is written).
 // ---------------------------------------------------------------------------
-template <class G, int ST>
+template <class G, int ST, bool SPL>
 __device__ void x3_chunk(const CtrgcArgs& a, int n, int c0, int t0, int bt, float* X3) {
     constexpr int V = G::V, NT = G::NT, CW = G::CW, NPF = G::NPF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -394,17 +394,39 @@ __device__ void x3_chunk(const CtrgcArgs& a, int n, int c0, int t0, int bt, floa
         if (k0 + SBK < a.Cin) prefetch(k0 + SBK);      // in flight under the MFMAs
         const float* at = As + j * SBKP + kq;
         const float* bt_ = Bs + kq * a.pitchB;
+        if constexpr (SPL) {
+            // split-fp32: the eight k = 4*k4 + kq this lane reads across the chunk form ONE K = 32 bf16 fragment
+            static_assert(SBK == 32, "one K = 32 step per chunk");
+            f32x4 a0[ST], a1[ST], b0[CW], b1[CW];
 #pragma unroll
-        for (int k4 = 0; k4 < SBK / 4; ++k4) {
-            float av[ST], bv[CW];
+            for (int k4 = 0; k4 < 4; ++k4) {
 #pragma unroll
-            for (int s = 0; s < ST; ++s) av[s] = at[s * 16 * SBKP + k4 * 4];
+                for (int s = 0; s < ST; ++s) { a0[s][k4] = at[s * 16 * SBKP + k4 * 4]; a1[s][k4] = at[s * 16 * SBKP + (k4 + 4) * 4]; }
 #pragma unroll
-            for (int c = 0; c < CW; ++c) bv[c] = bt_[k4 * 4 * a.pitchB + bcol[c]];
+                for (int c = 0; c < CW; ++c) { b0[c][k4] = bt_[k4 * 4 * a.pitchB + bcol[c]]; b1[c][k4] = bt_[(k4 + 4) * 4 * a.pitchB + bcol[c]]; }
+            }
+            bf16x8_t ah[ST], al[ST], bh[CW], bl[CW];
+#pragma unroll
+            for (int s = 0; s < ST; ++s) split_bf16x8(a0[s], a1[s], ah[s], al[s]);
+#pragma unroll
+            for (int c = 0; c < CW; ++c) split_bf16x8(b0[c], b1[c], bh[c], bl[c]);
 #pragma unroll
             for (int c = 0; c < CW; ++c)
 #pragma unroll
-                for (int s = 0; s < ST; ++s) acc[s][c] = mfma16(av[s], bv[c], acc[s][c]);
+                for (int s = 0; s < ST; ++s) acc[s][c] = mfma_split(ah[s], al[s], bh[c], bl[c], acc[s][c]);
+        } else {
+#pragma unroll
+            for (int k4 = 0; k4 < SBK / 4; ++k4) {
+                float av[ST], bv[CW];
+#pragma unroll
+                for (int s = 0; s < ST; ++s) av[s] = at[s * 16 * SBKP + k4 * 4];
+#pragma unroll
+                for (int c = 0; c < CW; ++c) bv[c] = bt_[k4 * 4 * a.pitchB + bcol[c]];
+#pragma unroll
+                for (int c = 0; c < CW; ++c)
+#pragma unroll
+                    for (int s = 0; s < ST; ++s) acc[s][c] = mfma16(av[s], bv[c], acc[s][c]);
+            }
         }
     }
     __syncthreads();                                   // stage dead; X3 may be overwritten
@@ -525,8 +547,8 @@ struct DyTile {
 // ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
-template <class G, int ST>
-__global__ __launch_bounds__(G::NT) void ctrgc_fwd_kernel(const CtrgcArgs a, float* y, float* stats_part, float* x3_out) {
+template <class G, int ST, bool SPL>
+__device__ __forceinline__ void ctrgc_fwd_body(const CtrgcArgs& a, float* y, float* stats_part, float* x3_out) {
     constexpr int V = G::V, TB = G::TB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int n, c0;
@@ -548,7 +570,7 @@ __global__ __launch_bounds__(G::NT) void ctrgc_fwd_kernel(const CtrgcArgs a, flo
         const int bt = min(G::BT, a.T - t0);
         const int ncols = bt * V;
         TG_T(ta);
-        x3_chunk<G, ST>(a, n, c0, t0, bt, X3);
+        x3_chunk<G, ST, SPL>(a, n, c0, t0, bt, X3);
         TG_T(tb); TG_ACC(1, tb - ta);
         float z[TB][G::UB];
 #pragma unroll
@@ -607,6 +629,15 @@ __global__ __launch_bounds__(G::NT) void ctrgc_fwd_kernel(const CtrgcArgs a, flo
             stats_part[((long long)1 * a.Cout + c0 + c) * a.N + n] = st2;
         }
     }
+}
+
+template <class G, int ST>
+__global__ __launch_bounds__(G::NT) void ctrgc_fwd_kernel(const CtrgcArgs a, float* y, float* stats_part, float* x3_out) {
+    ctrgc_fwd_body<G, ST, false>(a, y, stats_part, x3_out);      // exact fp32-input MFMA
+}
+template <class G, int ST>
+__global__ __launch_bounds__(G::NT) void ctrgc_fwd_split_kernel(const CtrgcArgs a, float* y, float* stats_part, float* x3_out) {
+    ctrgc_fwd_body<G, ST, true>(a, y, stats_part, x3_out);       // x3 GEMM as split-fp32 on the bf16 matrix cores
 }
 
 // ---------------------------------------------------------------------------
@@ -713,7 +744,7 @@ __global__ __launch_bounds__(G::NT) void ctrgc_bwd_de_kernel(const CtrgcArgs a, 
     for (int t0 = 0; t0 < a.T; t0 += G::BT) {
         const int bt = min(G::BT, a.T - t0);
         dyt.load(dy, n, c0, a.T, t0, bt);              // in flight under the x3 GEMM below
-        x3_chunk<G, ST>(a, n, c0, t0, bt, X3);         // begins with a barrier: previous chunk fully consumed
+        x3_chunk<G, ST, false>(a, n, c0, t0, bt, X3);  // begins with a barrier: previous chunk fully consumed
         dyt.commit(dy, Zs);
         __syncthreads();
         if (owner) {
@@ -974,7 +1005,11 @@ extern "C" int tamgcn_ctrgc_fwd(const tamgcn_ctrgc_desc* d, float* y, float* sta
     TG_CHECK(plan_ctrgc(d->S, d->V, &p) == 0, "tamgcn_ctrgc_fwd: unsupported S=%d V=%d (LDS-resident tiles exist for S in {1,3}, V in {20,25})", d->S, d->V);
     CtrgcArgs a;
     if (fill_args(d, p, &a, "tamgcn_ctrgc_fwd")) return -1;
-    CTRGC_DISPATCH(ctrgc_fwd_kernel, a, y, stats_part, x3_out);
+    // Split-fp32 in an ACTIVATION-producing GEMM is opt-in (mode 2): its 4e-6 relative error is twenty times the fp32
+    // rounding noise, flips correspondingly more ReLU masks, and end-to-end gradients then differ from the reference
+    // by ~1 % in places (tests/test_gpu_model.py strict case) although every tensor of the forward stays within 5e-6.
+    if (tamgcn_split_mode() >= 2) CTRGC_DISPATCH(ctrgc_fwd_split_kernel, a, y, stats_part, x3_out);
+    else CTRGC_DISPATCH(ctrgc_fwd_kernel, a, y, stats_part, x3_out);
     TG_LAUNCH_CHECK("tamgcn_ctrgc_fwd");
     return 0;
 }
