@@ -756,6 +756,188 @@ __global__ __launch_bounds__(G_NT, 2) void conv1x1_glds_kernel(const ConvArgs a,
     TG_T(tg1); TG_ACC(7, tg1 - tg0); TG_ACC(8, tg1 - tt0); TG_ACC(9, 1);
 }
 
+
+// ===========================================================================
+// Data-gradient form of the pointwise GEMM for wide layers (M >= 128, single source, w[k][m]):
+//   tile 128 channels x <= 320 columns, chunk of 32 contraction rows, two stages, split-fp32 MFMA.
+// The matrix work of dx <- dx3 at C >= 128 (K = 3C) is what bounds the fp32 kernel (65-75 TFLOP/s of the ~105 the
+// chip sustains); activation GRADIENTS never decide a ReLU mask, so the 4e-6 relative error of three
+// v_mfma_f32_16x16x32_bf16 stays a linear 1e-5-level perturbation (unlike in the forward, see ctrgc.hip).
+//   B image   as conv1x1_glds_kernel ([32][LB], odd rows rotated 16 columns)
+//   A image   [32][128]: dwordx4 pieces of 2 k rows, channel quads XOR-swizzled by 4*(k & 1) on the source address
+//   fragment  lane (j, kq) owns k = 4e + kq, e = 0..7: ONE K = 32 step per chunk; B of a column tile is split once and
+//             meets the four row tiles' pre-split A fragments
+// ===========================================================================
+constexpr int GS_BK = 32, GS_BMT = 128, GS_MT = 4, GS_NST = 2;
+
+__global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs a, int ntt, int nmt) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int BK = GS_BK;
+    constexpr int STG = BK * G_PBMAX + BK * GS_BMT;               // floats per stage
+    constexpr int MAXB = ((BK / 4) * 5 + 7) / 8;                  // B pieces per wave and chunk
+    constexpr int NAP = BK * GS_BMT / 256 / 8;                    // A pieces per wave and chunk (2)
+    float* cf = smem + GS_NST * STG;                              // [3][K]
+    float* Ss = cf + 3 * a.K;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kq = lane >> 4, wm = wave >> 2, wn = wave & 3;
+    const int V = a.V, K = a.K, LB = a.LB;
+    int g, mtile;
+    {
+        const int L = blockIdx.x, ng = a.N * ntt;
+        if ((ng & 7) == 0) { const int xcd = L & 7, i = L >> 3; mtile = i % nmt; g = (i / nmt) * 8 + xcd; }
+        else { g = L / nmt; mtile = L - g * nmt; }
+    }
+    const int n = g / ntt, tt = g - n * ntt;
+    const int m0 = mtile * GS_BMT, t0 = tt * a.BT;
+    const int bt = min(a.BT, a.T_out - t0);
+    const int ncols = bt * V;
+    const long long TV = (long long)a.T_in * V;
+
+    for (int e = tid; e < K; e += G_NT) {
+        int ch = a.src.coff + e;
+        cf[e] = a.src.coef ? a.src.coef[ch] : 1.f;
+        cf[2 * K + e] = a.src.coef ? a.src.coef[2 * a.src.ctot + ch] : 0.f;
+    }
+    const bool plain = !a.src.coef && a.src.act != 1;
+
+    // ---- B pieces (as in conv1x1_glds_kernel)
+    const int NQ = (LB + 63) >> 6, NI1 = (BK / 4) * NQ;
+    int b_rel[MAXB], b_dst[MAXB];
+    bool b_ok[MAXB], b_on[MAXB];
+    int nissue = 0;
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i) {
+        const int id = wave + i * 8;
+        const bool idok = id < NI1;
+        const int grp = (idok ? id : 0) / NQ, q = (idok ? id : 0) - grp * NQ;
+        const int f = q * 256 + lane * 4;
+        const int r = f / LB, off = f - r * LB;
+        int col = off + ((r & 1) << 4);
+        if (col >= LB) col -= LB;
+        b_ok[i] = idok && r < 4 && col < ncols;
+        b_rel[i] = (int)((grp * 4 + r) * TV) + col;
+        b_dst[i] = grp * 4 * LB + q * 256;
+        b_on[i] = __ballot(b_ok[i]) != 0ull;
+        nissue += b_on[i] ? 1 : 0;
+    }
+    const float* xb1 = a.src.x1 + ((long long)n * a.src.ctot + a.src.coff) * TV + (long long)t0 * V;
+    // ---- A pieces: piece p of this wave covers k rows 2p', lanes 0-31 row 2p', lanes 32-63 row 2p'+1; 32 quads of 4 channels
+    int a_rel[NAP], a_dst[NAP];
+    bool a_ok[NAP];
+#pragma unroll
+    for (int i = 0; i < NAP; ++i) {
+        const int piece = wave * NAP + i;                         // 0..15
+        const int kr = piece * 2 + (lane >> 5), q = lane & 31;    // k row in the chunk, physical channel quad
+        const int qs = q ^ ((kr & 1) << 2);                       // source quad: rows of different parity sit 16 banks apart
+        a_ok[i] = m0 + qs * 4 < a.M;                              // M % 4 == 0 (host)
+        a_rel[i] = kr * (int)a.ws_k + (m0 + qs * 4) * (int)a.ws_m;
+        a_dst[i] = BK * G_PBMAX + piece * 256;
+    }
+    nissue += NAP;
+    auto issue = [&](int c) {
+        float* st = smem + (c % GS_NST) * STG;
+        const int k0 = c * BK;
+#pragma unroll
+        for (int i = 0; i < NAP; ++i)
+            if (a_ok[i]) __builtin_amdgcn_global_load_lds((tg_gptr)(a.w + a.w_off + (long long)k0 * a.ws_k + a_rel[i]), (tg_lptr)(st + a_dst[i]), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MAXB; ++i) {
+            if (b_on[i]) {
+                const float* gp = xb1 + (long long)k0 * TV + b_rel[i];
+                if (b_ok[i]) __builtin_amdgcn_global_load_lds((tg_gptr)gp, (tg_lptr)(st + b_dst[i]), 16, 0, 0);
+            }
+        }
+    };
+
+    int bslot[G_CWT];
+#pragma unroll
+    for (int c = 0; c < G_CWT; ++c) {
+        int col = (wn * G_CWT + c) * 16 + j;
+        if (col >= ncols) col = 0;
+        int sl = col - ((kq & 1) << 4);
+        bslot[c] = sl < 0 ? sl + LB : sl;
+    }
+    int aoff[GS_MT];                                               // channel of row tile mt, swizzled for this lane's k parity
+#pragma unroll
+    for (int mt = 0; mt < GS_MT; ++mt) {
+        const int m = wm * 64 + mt * 16 + j;
+        aoff[mt] = (((m >> 2) ^ ((kq & 1) << 2)) << 2) + (m & 3);
+    }
+    f32x4 acc[GS_MT][G_CWT];
+#pragma unroll
+    for (int mt = 0; mt < GS_MT; ++mt)
+#pragma unroll
+        for (int c = 0; c < G_CWT; ++c) acc[mt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float lo = a.src.act == 1 ? 0.f : -__builtin_inff();
+
+    __syncthreads();
+    const int nch = K / BK;
+    issue(0);
+    for (int c = 0; c < nch; ++c) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (c + 1 < nch) issue(c + 1);
+        const float* st = smem + (c % GS_NST) * STG;
+        const float* As = st + BK * G_PBMAX;
+        const int k0 = c * BK;
+        bf16x8_t ah[GS_MT], al[GS_MT];
+#pragma unroll
+        for (int mt = 0; mt < GS_MT; ++mt) {
+            f32x4 v0, v1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v0[e] = As[(4 * e + kq) * GS_BMT + aoff[mt]]; v1[e] = As[(4 * (e + 4) + kq) * GS_BMT + aoff[mt]]; }
+            split_bf16x8(v0, v1, ah[mt], al[mt]);
+        }
+        float c1[8], c0[8];
+        if (!plain) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { c1[e] = cf[k0 + 4 * e + kq]; c0[e] = cf[2 * K + k0 + 4 * e + kq]; }
+        }
+#pragma unroll
+        for (int cc = 0; cc < G_CWT; ++cc) {
+            f32x4 v0, v1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v0[e] = st[(4 * e + kq) * LB + bslot[cc]]; v1[e] = st[(4 * (e + 4) + kq) * LB + bslot[cc]]; }
+            if (!plain) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(fmaf(c1[e], v0[e], c0[e]), lo); v1[e] = fmaxf(fmaf(c1[e + 4], v1[e], c0[e + 4]), lo); }
+            }
+            bf16x8_t bh, bl;
+            split_bf16x8(v0, v1, bh, bl);
+#pragma unroll
+            for (int mt = 0; mt < GS_MT; ++mt) acc[mt][cc] = mfma_split(ah[mt], al[mt], bh, bl, acc[mt][cc]);
+        }
+    }
+
+    // ---- staged epilogue: four passes of 32 rows
+    constexpr int PT = G_CWT * 64 + 4, RP = 32;
+    float* Tt = smem;
+    const int nc4 = ncols >> 2;
+    if (a.stats_part) {
+        for (int e = tid; e < 2 * 4 * BM; e += G_NT) Ss[e] = 0.f;
+    }
+    for (int r0 = 0; r0 < GS_BMT; r0 += RP) {
+        __syncthreads();
+        if (wm * 64 <= r0 && r0 < wm * 64 + 64) {
+            const int mtb = (r0 - wm * 64) / 16;                  // this pass = row tiles mtb, mtb+1 of the wave
+#pragma unroll
+            for (int mt2 = 0; mt2 < 2; ++mt2)
+#pragma unroll
+                for (int c = 0; c < G_CWT; ++c) {
+                    const int col = (wn * G_CWT + c) * 16 + j;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const f32x4 v = mtb == 0 ? acc[mt2][c] : acc[2 + mt2][c];
+                        Tt[(mt2 * 16 + kq * 4 + r) * PT + col] = v[r];
+                    }
+                }
+        }
+        __syncthreads();
+        staged_rows<G_NT>(a, Tt, PT, RP, r0, GS_BMT, m0, n, t0, nc4, Ss + 0);
+    }
+}
+
 template <int NSRC, int BK>
 constexpr size_t glds_lds_bytes(int K) {
     return sizeof(float) * ((size_t)G_NST * (BK * G_PBMAX * NSRC + BK * G_PA) + 3 * (size_t)K + 2 * 4 * BM);
@@ -846,7 +1028,18 @@ extern "C" int tamgcn_conv(const tamgcn_conv_desc* d, void* stream) {
     const bool glds = p.vec && d->KT == 1 && d->stride == 1 && d->up == 1 && d->ostride == 1 && d->pad == 0 &&
                       d->T_in == d->T_out && d->T_y == d->T_out && d->K % 16 == 0 && p.LB >= 64 && p.LB <= G_PBMAX &&
                       aligned16 && (long long)d->K * d->T_in * d->V < (1LL << 30);
-    if (glds) {
+    const bool big = glds && tamgcn_split_mode() >= 1 && d->wmode == 1 && !d->src.x2 && d->M >= 128 && d->M % 4 == 0 &&
+                     d->K % GS_BK == 0 && !d->stats_part;
+    if (big) {
+        const int nmt = ceil_div(d->M, GS_BMT);
+        const unsigned nblk = (unsigned)(d->N * p.ntt * nmt);
+        static bool fs = false;
+        const size_t lds = sizeof(float) * ((size_t)GS_NST * (GS_BK * G_PBMAX + GS_BK * GS_BMT) + 3 * (size_t)d->K + 2 * 4 * BM);
+        if (!fs) { (void)hipFuncSetAttribute((const void*)conv1x1_glds_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); fs = true; }
+        TG_CHECK(lds <= 160 * 1024, "tamgcn_conv: K=%d too large for the split data-gradient kernel", d->K);
+        hipLaunchKernelGGL(conv1x1_glds_split_kernel, dim3(nblk), dim3(G_NT), lds, (hipStream_t)stream, a, p.ntt, nmt);
+        tamgcn_note_kernel("conv1x1_glds_split_kernel");
+    } else if (glds) {
         const int nmt = ceil_div(d->M, G_BMT);
         const unsigned nblk = (unsigned)(d->N * p.ntt * nmt);
         if (d->src.x2) {
