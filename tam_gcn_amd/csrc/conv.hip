@@ -797,9 +797,14 @@ __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs
     for (int e = tid; e < K; e += G_NT) {
         int ch = a.src.coff + e;
         cf[e] = a.src.coef ? a.src.coef[ch] : 1.f;
+        cf[K + e] = (a.src.coef && a.src.x2) ? a.src.coef[a.src.ctot + ch] : 0.f;
         cf[2 * K + e] = a.src.coef ? a.src.coef[2 * a.src.ctot + ch] : 0.f;
     }
-    const bool plain = !a.src.coef && a.src.act != 1;
+    // The operand is LINEAR here (act == 0, host-checked): W^T (c1 x1 + c2 x2 + c0) = (W c1)^T x1 + (W c2)^T x2 + W^T c0.
+    // The coefficients scale the A fragment, a second source is just K more contraction rows, and the constant term
+    // is a per-channel bias the lanes accumulate from their A values: B is never touched by the prologue.
+    const bool plain = !a.src.coef;
+    const int nsrc = a.src.x2 ? 2 : 1;
 
     // ---- B pieces (as in conv1x1_glds_kernel)
     const int NQ = (LB + 63) >> 6, NI1 = (BK / 4) * NQ;
@@ -821,7 +826,10 @@ __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs
         b_on[i] = __ballot(b_ok[i]) != 0ull;
         nissue += b_on[i] ? 1 : 0;
     }
-    const float* xb1 = a.src.x1 + ((long long)n * a.src.ctot + a.src.coff) * TV + (long long)t0 * V;
+    const long long xoff = ((long long)n * a.src.ctot + a.src.coff) * TV + (long long)t0 * V;
+    const float* xb1 = a.src.x1 + xoff;
+    const float* xb2 = a.src.x2 ? a.src.x2 + xoff : nullptr;
+    const int nchk = K / BK;                                      // chunks per source
     // ---- A pieces: piece p of this wave covers k rows 2p', lanes 0-31 row 2p', lanes 32-63 row 2p'+1; 32 quads of 4 channels
     int a_rel[NAP], a_dst[NAP];
     bool a_ok[NAP];
@@ -837,14 +845,15 @@ __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs
     nissue += NAP;
     auto issue = [&](int c) {
         float* st = smem + (c % GS_NST) * STG;
-        const int k0 = c * BK;
+        const int k0 = (c % nchk) * BK;
+        const float* xb = c < nchk ? xb1 : xb2;
 #pragma unroll
         for (int i = 0; i < NAP; ++i)
             if (a_ok[i]) __builtin_amdgcn_global_load_lds((tg_gptr)(a.w + a.w_off + (long long)k0 * a.ws_k + a_rel[i]), (tg_lptr)(st + a_dst[i]), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < MAXB; ++i) {
             if (b_on[i]) {
-                const float* gp = xb1 + (long long)k0 * TV + b_rel[i];
+                const float* gp = xb + (long long)k0 * TV + b_rel[i];
                 if (b_ok[i]) __builtin_amdgcn_global_load_lds((tg_gptr)gp, (tg_lptr)(st + b_dst[i]), 16, 0, 0);
             }
         }
@@ -869,10 +878,10 @@ __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs
     for (int mt = 0; mt < GS_MT; ++mt)
 #pragma unroll
         for (int c = 0; c < G_CWT; ++c) acc[mt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float lo = a.src.act == 1 ? 0.f : -__builtin_inff();
+    float bsum[GS_MT] = {0.f, 0.f, 0.f, 0.f};                     // this lane's share of (W^T c0)[m]
 
     __syncthreads();
-    const int nch = K / BK;
+    const int nch = nsrc * nchk;
     issue(0);
     for (int c = 0; c < nch; ++c) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -880,29 +889,33 @@ __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs
         if (c + 1 < nch) issue(c + 1);
         const float* st = smem + (c % GS_NST) * STG;
         const float* As = st + BK * G_PBMAX;
-        const int k0 = c * BK;
+        const int k0 = (c % nchk) * BK;
+        float cs[8], c0[8];                                         // scale of this chunk's rows, constant term (first source only)
+        if (!plain) {
+            const float* cc1 = cf + (c < nchk ? 0 : K) + k0 + kq;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { cs[e] = cc1[4 * e]; c0[e] = c < nchk ? cf[2 * K + k0 + 4 * e + kq] : 0.f; }
+        }
         bf16x8_t ah[GS_MT], al[GS_MT];
 #pragma unroll
         for (int mt = 0; mt < GS_MT; ++mt) {
             f32x4 v0, v1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v0[e] = As[(4 * e + kq) * GS_BMT + aoff[mt]]; v1[e] = As[(4 * (e + 4) + kq) * GS_BMT + aoff[mt]]; }
-            split_bf16x8(v0, v1, ah[mt], al[mt]);
-        }
-        float c1[8], c0[8];
-        if (!plain) {
+            if (!plain) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { c1[e] = cf[k0 + 4 * e + kq]; c0[e] = cf[2 * K + k0 + 4 * e + kq]; }
+                for (int e = 0; e < 4; ++e) {
+                    bsum[mt] = fmaf(v0[e], c0[e], fmaf(v1[e], c0[e + 4], bsum[mt]));
+                    v0[e] *= cs[e]; v1[e] *= cs[e + 4];
+                }
+            }
+            split_bf16x8(v0, v1, ah[mt], al[mt]);
         }
 #pragma unroll
         for (int cc = 0; cc < G_CWT; ++cc) {
             f32x4 v0, v1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v0[e] = st[(4 * e + kq) * LB + bslot[cc]]; v1[e] = st[(4 * (e + 4) + kq) * LB + bslot[cc]]; }
-            if (!plain) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(fmaf(c1[e], v0[e], c0[e]), lo); v1[e] = fmaxf(fmaf(c1[e + 4], v1[e], c0[e + 4]), lo); }
-            }
             bf16x8_t bh, bl;
             split_bf16x8(v0, v1, bh, bl);
 #pragma unroll
@@ -910,12 +923,17 @@ __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs
         }
     }
 
-    // ---- staged epilogue: four passes of 32 rows
+    // ---- staged epilogue: four passes of 32 rows.  The constant term W^T c0: sum over the four kq lanes of a row,
+    // one column-wave per row group publishes it (Ss is free: this kernel produces no moments).
     constexpr int PT = G_CWT * 64 + 4, RP = 32;
     float* Tt = smem;
     const int nc4 = ncols >> 2;
-    if (a.stats_part) {
-        for (int e = tid; e < 2 * 4 * BM; e += G_NT) Ss[e] = 0.f;
+    float* Bc = Ss;                                               // [128] per-row constant
+#pragma unroll
+    for (int mt = 0; mt < GS_MT; ++mt) {
+        float t = bsum[mt];
+        t += __shfl_xor(t, 16); t += __shfl_xor(t, 32);
+        if (wn == 0 && kq == 0) Bc[wm * 64 + mt * 16 + j] = t;
     }
     for (int r0 = 0; r0 < GS_BMT; r0 += RP) {
         __syncthreads();
@@ -929,7 +947,7 @@ __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const f32x4 v = mtb == 0 ? acc[mt2][c] : acc[2 + mt2][c];
-                        Tt[(mt2 * 16 + kq * 4 + r) * PT + col] = v[r];
+                        Tt[(mt2 * 16 + kq * 4 + r) * PT + col] = v[r] + Bc[r0 + mt2 * 16 + kq * 4 + r];
                     }
                 }
         }
@@ -1028,7 +1046,7 @@ extern "C" int tamgcn_conv(const tamgcn_conv_desc* d, void* stream) {
     const bool glds = p.vec && d->KT == 1 && d->stride == 1 && d->up == 1 && d->ostride == 1 && d->pad == 0 &&
                       d->T_in == d->T_out && d->T_y == d->T_out && d->K % 16 == 0 && p.LB >= 64 && p.LB <= G_PBMAX &&
                       aligned16 && (long long)d->K * d->T_in * d->V < (1LL << 30);
-    const bool big = glds && tamgcn_split_mode() >= 1 && d->wmode == 1 && !d->src.x2 && d->M >= 128 && d->M % 4 == 0 &&
+    const bool big = glds && tamgcn_split_mode() >= 1 && d->wmode == 1 && d->src.act == 0 && d->M >= 128 && d->M % 4 == 0 &&
                      d->K % GS_BK == 0 && !d->stats_part;
     if (big) {
         const int nmt = ceil_div(d->M, GS_BMT);
