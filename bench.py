@@ -333,7 +333,13 @@ def main():
     _log(f'timed {args.steps} steps in {dt:.3f}s ({mode})')
 
     out = None
+    # Per-kernel durations for the roofline: the same step, launched eagerly on ONE stream, HIP events around every ABI
+    # launch.  (With the side streams on, kernels overlap and an event pair measures the overlap, not the kernel:
+    # rocprofv3 --kernel-trace of that mode reports the same inflated durations.)
+    from tam_gcn_amd import functional as _F
+    side, _F.USE_SIDE_STREAMS = _F.USE_SIDE_STREAMS, False
     agg = instrumented_pass(eager_step, probe, 2)         # every rank: the step contains a collective
+    _F.USE_SIDE_STREAMS = side
     _log('instrumented pass done')
     if rank == 0:
         roof, shares = roofline_of(agg)

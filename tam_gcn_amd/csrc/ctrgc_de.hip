@@ -199,8 +199,10 @@ constexpr int tail_pitch(int vv) {   // smallest pitch >= vv with pitch % 16 == 
 }
 
 template <int V, int RT>
-__global__ __launch_bounds__(256) void ctrgc_de_tail_kernel(const TailArgs a) {
-    constexpr int VV = V * V, PD = tail_pitch(VV), NT = 256, NW = 4;
+__global__ __launch_bounds__(512) void ctrgc_de_tail_kernel(const TailArgs a) {
+    // 512 threads: the kernel holds one workgroup per CU at R = 32 (D alone is 51 KB), so parallelism inside the
+    // workgroup is what hides its latencies (256 threads = one wave per SIMD measured 400 us at C = 256)
+    constexpr int VV = V * V, PD = tail_pitch(VV), NT = 512, NW = 8;
     constexpr int NCT = (VV + 15) / 16, TPW = (NCT + NW - 1) / NW;
     constexpr int NA = (VV + NT - 1) / NT;
     constexpr int NCH = (16 * VV / 4 + NT - 1) / NT;
@@ -227,26 +229,31 @@ __global__ __launch_bounds__(256) void ctrgc_de_tail_kernel(const TailArgs a) {
         }
     };
     load(cbeg);
-    {   // D[r][uv] = tanh(p[r][u] - q[r][v]); four (p, q) pairs in flight per thread
-        const float* pb = a.pq + ((long long)(s * 2 + 0) * a.R) * NV + (long long)n * V;
-        const float* qb = a.pq + ((long long)(s * 2 + 1) * a.R) * NV + (long long)n * V;
-        const int total = a.R * VV;
-        for (int e0 = tid; e0 < total; e0 += 4 * NT) {
-            float pv[4], qv[4];
-            int off[4];
+    {   // p, q of this (n, subset) -> LDS in one batch of loads, then D[r][uv] = tanh(p[r][u] - q[r][v]) from LDS
+        // (reading p, q per element from L2 was a dozen dependent round trips per thread)
+        float* PQ = red + NW * 16 * RT * 16;                       // [p | q][R][V]
+        const int cnt = 2 * a.R * V;
+        constexpr int MAXL = 8;
+        for (int e0 = tid; e0 < cnt; e0 += MAXL * NT) {
+            float t[MAXL];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int e = e0 + i * NT;
-                int ec = e < total ? e : 0;
-                int r = ec / VV, uv = ec - r * VV;
-                int u = uv / V, v = uv - u * V;
-                pv[i] = pb[r * NV + u];
-                qv[i] = qb[r * NV + v];
-                off[i] = e < total ? r * PD + uv : -1;
+            for (int i = 0; i < MAXL; ++i) {
+                const int e = e0 + i * NT;
+                const int row = (e < cnt ? e : 0) / V, v = (e < cnt ? e : 0) - row * V;
+                t[i] = a.pq[((long long)s * 2 * a.R + row) * NV + (long long)n * V + v];
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (off[i] >= 0) Ds[off[i]] = fast_tanh(pv[i] - qv[i]);
+            for (int i = 0; i < MAXL; ++i) {
+                const int e = e0 + i * NT;
+                if (e < cnt) PQ[e] = t[i];
+            }
+        }
+        __syncthreads();
+        const int total = a.R * VV;
+        for (int e = tid; e < total; e += NT) {
+            const int r = e / VV, uv = e - r * VV;
+            const int u = uv / V, v = uv - u * V;
+            Ds[r * PD + uv] = fast_tanh(PQ[r * V + u] - PQ[(a.R + r) * V + v]);
         }
     }
     f32x4 accG[TPW][RT];
@@ -311,16 +318,16 @@ __global__ __launch_bounds__(256) void ctrgc_de_tail_kernel(const TailArgs a) {
         }
         // db4raw[c] = sum_uv dE[c][uv]
         {
-            const int c = tid >> 4, l16 = tid & 15;
+            const int c = (tid >> 4) & 15, l16 = tid & 15;          // threads 256.. shadow 0..255 (no second write)
             float t = 0.f;
             for (int uv = l16; uv < VV; uv += 16) t += DEs[c * PD + uv];
             t = wave_sum16(t);
-            if (l16 == 0) {
+            if (l16 == 0 && tid < 256) {
                 a.db4_part[((long long)n * a.S + s) * a.Cout + c0 + c] = alpha * t;
                 dalpha_acc = fmaf(a.b4[s * a.Cout + c0 + c], t, dalpha_acc);
             }
         }
-        // dW4raw[c][r] = sum_uv dE[c][uv] D[r][uv]: K = VV split over the four waves
+        // dW4raw[c][r] = sum_uv dE[c][uv] D[r][uv]: K = VV split over the waves
         {
             f32x4 accW[RT];
 #pragma unroll
@@ -397,7 +404,11 @@ __global__ __launch_bounds__(256) void ctrgc_de_tail_kernel(const TailArgs a) {
     dalpha_acc = wave_sum64(dalpha_acc);
     if (lane == 0) red_alpha[wave] = dalpha_acc;
     __syncthreads();
-    if (tid == 0) a.dalpha_part[(n * a.S + s) * a.G + grp] = red_alpha[0] + red_alpha[1] + red_alpha[2] + red_alpha[3];
+    if (tid == 0) {
+        float t = 0.f;
+        for (int w = 0; w < NW; ++w) t += red_alpha[w];
+        a.dalpha_part[(n * a.S + s) * a.G + grp] = t;
+    }
 }
 
 template <typename K>
@@ -409,7 +420,7 @@ void allow_lds(K kernel, size_t lds, bool* done) {
 }
 
 template <int V>
-size_t tail_lds(int R, int RT) { return sizeof(float) * ((size_t)(R + 16) * tail_pitch(V * V) + 4 * 16 * RT * 16); }
+size_t tail_lds(int R, int RT) { return sizeof(float) * ((size_t)(R + 16) * tail_pitch(V * V) + 8 * 16 * RT * 16 + 2 * (size_t)R * V); }
 
 }  // namespace
 
@@ -440,7 +451,7 @@ extern "C" int tamgcn_ctrgc_bwd_de_acc(const tamgcn_ctrgc_desc* d, const tamgcn_
         static bool flag = false;                                                                                      \
         const size_t lds = tail_lds<VV_>(d->R, RT_);                                                                   \
         allow_lds(ctrgc_de_tail_kernel<VV_, RT_>, tail_lds<VV_>(32, 2), &flag);                                        \
-        hipLaunchKernelGGL((ctrgc_de_tail_kernel<VV_, RT_>), dim3(d->N * d->S * groups), dim3(256), lds, (hipStream_t)stream, a); \
+        hipLaunchKernelGGL((ctrgc_de_tail_kernel<VV_, RT_>), dim3(d->N * d->S * groups), dim3(512), lds, (hipStream_t)stream, a); \
         tamgcn_note_kernel("ctrgc_de_tail_kernel<%d, %d>", VV_, RT_);                                                  \
         launched = true;                                                                                               \
     }

@@ -217,7 +217,8 @@ def ctrgc_bwd_de(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy, x3=None):
         dE = empty(N, S, Cout, V, V, like=like)
         _lib.check(_lib_().tamgcn_ctrgc_bwd_de_acc(C.byref(d), C.byref(dyc), _ptr(x3), _ptr(dE), _stream()),
                    'tamgcn_ctrgc_bwd_de_acc')
-        G = max(1, min(4, Cout // 64))                 # channel groups per (n, subset): parallelism for wide layers
+        G = 1                                           # channel groups per (n, subset); the per-workgroup fixed cost (D fill,
+        #                                               dp/dq sums) equals ~1.4 channel chunks, so splitting did not pay (measured)
         while Cout % (16 * G):
             G -= 1
         dA_part = empty(N * G, S, V, V, like=like)
