@@ -1168,18 +1168,21 @@ __device__ __forceinline__ void wg_fill(float* tile, int pitch, const float* cf,
 
 constexpr int WG_NPF = 6;     // float4 prefetch slots per thread and operand (1x1 weight-gradient pipeline)
 
-template <int KT, int WMT, int WKT, bool VEC>
+// PS ("p-split", M, K <= 16: the 16-channel temporal branches): the tile is ONE 16x16 MFMA tile; instead of tiling
+// (M, K) 2x2 -- three of four waves would idle -- the four waves share it and split the chunk's frames, partial
+// accumulators meet in LDS at the end.
+template <int KT, int WMT, int WKT, bool VEC, bool PS = false>
 __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int BMW = 2 * WMT * 16, BKW = 2 * WKT * 16;
-    constexpr bool PF = VEC && KT == 1;       // register-prefetch pipeline (host guarantees the slot bound)
+    constexpr int BMW = PS ? 16 : 2 * WMT * 16, BKW = PS ? 16 : 2 * WKT * 16;
+    constexpr bool PF = VEC && (KT == 1 || PS);   // register-prefetch pipeline (host guarantees the slot bound)
     float* Ys = smem;                         // [BMW][PY]
     float* Xs = Ys + BMW * a.PY;              // [BKW][PX]
     float* cfY = Xs + BKW * a.PX;             // [3][BMW]
     float* cfX = cfY + 3 * BMW;               // [3][BKW]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kq = lane >> 4;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = PS ? 0 : wave >> 1, wc = PS ? 0 : wave & 1;
     const int k0 = blockIdx.x * BKW, m0 = blockIdx.y * BMW, split = blockIdx.z;
     const int V = a.V, V4 = (V + 3) >> 2;
     // a split owns a contiguous range of the (sample, frame chunk) sequence: splits may be finer than samples
@@ -1301,7 +1304,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(const WgradArgs a) {
             if constexpr (PF) {               // next chunk's loads fly under this chunk's MFMAs
                 if (ci + 1 < c_end) prefetch((ci + 1) / cpt, ((ci + 1) % cpt) * a.BT);
             }
-            for (int tl = 0; tl < bt; ++tl) {
+            for (int tl = PS ? wave : 0; tl < bt; tl += PS ? 4 : 1) {
 #pragma unroll 5
                 for (int v4 = 0; v4 < V4; ++v4) {
                     int v = v4 * 4 + kq;
@@ -1328,6 +1331,26 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(const WgradArgs a) {
         }
     }
     float* out = a.part + (long long)split * a.M * a.K * KT;
+    if constexpr (PS) {                       // sum the four waves' partial tiles through LDS (operand tiles are dead)
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < KT; ++tap)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) smem[(wave * KT + tap) * 256 + lane * 4 + r] = acc[tap][0][0][r];
+        __syncthreads();
+        const int l = tid >> 2, r = tid & 3;
+        const int m = m0 + (l >> 4) * 4 + r, k = k0 + (l & 15);
+        if (m < a.M && k < a.K) {
+#pragma unroll
+            for (int tap = 0; tap < KT; ++tap) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) t += smem[(w * KT + tap) * 256 + tid];
+                out[((long long)m * a.K + k) * KT + tap] = t;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int tap = 0; tap < KT; ++tap)
 #pragma unroll
@@ -1568,9 +1591,9 @@ static inline int even_pitch(int n) {      // smallest p >= n with p == 2 (mod 4
     return p + 2;
 }
 
-template <int KT, int WMT, int WKT>
+template <int KT, int WMT, int WKT, bool PS = false>
 static int launch_wgrad(WgradArgs& a, hipStream_t s) {
-    constexpr int BMW = 2 * WMT * 16, BKW = 2 * WKT * 16;
+    constexpr int BMW = PS ? 16 : 2 * WMT * 16, BKW = PS ? 16 : 2 * WKT * 16;
     const int V = a.V;
     const bool vec = (V % 4) == 0;
     int BT = 8;
@@ -1582,8 +1605,9 @@ static int launch_wgrad(WgradArgs& a, hipStream_t s) {
         a.PY = even_pitch(BT * V);
         a.PX = even_pitch(a.TIN * V);
         lds = sizeof(float) * ((size_t)BMW * a.PY + (size_t)BKW * a.PX + 3 * (BMW + BKW));
-        bool slots_ok = !(vec && KT == 1) ||
+        bool slots_ok = !(vec && (KT == 1 || PS)) ||
                         (BMW * (BT * V / 4) <= WG_NPF * NTHREADS && BKW * (a.TIN * V / 4) <= WG_NPF * NTHREADS);
+        if (PS && lds < sizeof(float) * 4 * KT * 256) lds = sizeof(float) * 4 * KT * 256;   // the final cross-wave reduction
         if ((lds <= 48 * 1024 && slots_ok) || BT == 1) {
             if (!slots_ok) { tamgcn_set_error("tamgcn_wgrad: prefetch slots exceeded (V=%d stride=%d)", V, a.stride); return -1; }
             break;
@@ -1592,11 +1616,11 @@ static int launch_wgrad(WgradArgs& a, hipStream_t s) {
     }
     if (lds > 160 * 1024) { tamgcn_set_error("tamgcn_wgrad: tile does not fit LDS (V=%d)", V); return -1; }
     a.n_per = ceil_div(a.N * ceil_div(a.T_out, a.BT), a.nsplit);          // frame chunks per split
-    tamgcn_note_kernel("wgrad_kernel<%d, %d, %d, %s>", KT, WMT, WKT, vec ? "true" : "false");
+    tamgcn_note_kernel("wgrad_kernel<%d, %d, %d, %s%s>", KT, WMT, WKT, vec ? "true" : "false", PS ? ", p-split" : "");
     dim3 grid(ceil_div(a.K, BKW), ceil_div(a.M, BMW), a.nsplit);
     if (vec) {
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)wgrad_kernel<KT, WMT, WKT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((wgrad_kernel<KT, WMT, WKT, true>), grid, dim3(NTHREADS), lds, s, a);
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)wgrad_kernel<KT, WMT, WKT, true, PS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((wgrad_kernel<KT, WMT, WKT, true, PS>), grid, dim3(NTHREADS), lds, s, a);
     } else {
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)wgrad_kernel<KT, WMT, WKT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((wgrad_kernel<KT, WMT, WKT, false>), grid, dim3(NTHREADS), lds, s, a);
@@ -1691,7 +1715,10 @@ extern "C" int tamgcn_wgrad(const tamgcn_wgrad_desc* d, void* stream) {
             else rc = launch_wgrad<1, 4, 4>(a, s);
             break;
         case 3: rc = wmt == 1 ? launch_wgrad<3, 1, 1>(a, s) : launch_wgrad<3, 2, 2>(a, s); break;
-        case 5: rc = wmt == 1 ? launch_wgrad<5, 1, 1>(a, s) : launch_wgrad<5, 2, 2>(a, s); break;
+        case 5:
+            if (d->M <= 16 && d->K <= 16 && d->V % 4 == 0) rc = launch_wgrad<5, 1, 1, true>(a, s);
+            else rc = wmt == 1 ? launch_wgrad<5, 1, 1>(a, s) : launch_wgrad<5, 2, 2>(a, s);
+            break;
         case 9: rc = launch_wgrad<9, 1, 1>(a, s); break;
         default: tamgcn_set_error("tamgcn_wgrad: kernel size %d not instantiated (1,3,5,9)", d->KT); return -1;
     }

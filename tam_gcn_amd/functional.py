@@ -59,6 +59,18 @@ class Fork:
         for i in self.used:
             self.side[i].wait_stream(self.main)
 
+    def mark(self, i):
+        """Event after what side stream i has been given so far; main.wait_event(it) later joins THAT point only."""
+        if not self.side or (i % len(self.side)) not in self.used:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self.side[i % len(self.side)])
+        return ev
+
+    def wait(self, ev):
+        if ev is not None:
+            self.main.wait_event(ev)
+
     def join(self, i):
         """main waits for side stream i now (its results are needed on main)."""
         if self.side and (i % len(self.side)) in self.used:
@@ -331,24 +343,32 @@ def tcn_backward(P, sv, dout, need_dg=True, need_dxres=True):
     G['Wt'] = []
     G['bn_in'] = []
     dbin = []
+    # temporal branches: branch 0's data gradient on main, the others' beside it (small, latency-bound launches);
+    # every branch's weight gradient follows on a side stream
+    marks = []
     for b in range(nb):
         k, d = P.ks[b], P.dils[b]
         pad = _tpad(k, d)
-        _, hp = ops.conv(gcat(b * Cb), K=Cb, w=P.Wt[b], bias=None, M=Cb, KT=k, dil=d, stride=1,
-                         pad=(k - 1) * d - pad, wmode=1, up=s, y=dh, ycoff=b * Cb, T_out=T,
-                         mask=S(h_pre, coef=sv['coef_h'], coff=b * Cb), aux=h_pre, aux_center=sv['save_h'], auxcoff=b * Cb,
-                         stats=True)
+        with (fk.on(b) if b > 0 else contextlib.nullcontext()):
+            _, hp = ops.conv(gcat(b * Cb), K=Cb, w=P.Wt[b], bias=None, M=Cb, KT=k, dil=d, stride=1,
+                             pad=(k - 1) * d - pad, wmode=1, up=s, y=dh, ycoff=b * Cb, T_out=T,
+                             mask=S(h_pre, coef=sv['coef_h'], coff=b * Cb), aux=h_pre, aux_center=sv['save_h'], auxcoff=b * Cb,
+                             stats=True)
+            dgam, dbet, dbias = P.bn_in[b].bwd(hp, b * Cb, cnt1, sv['save_h'], b * Cb, training, coefb_h, b * Cb, True)
+        if b > 0:
+            marks.append(fk.mark(b))                   # dh slice + coefficients of branch b done (its wgrad is not awaited)
+        G['bn_in'].append((dgam, dbet))
+        dbin.append(dbias)
         with fk.on(b):
             G['Wt'].append(ops.wgrad(gcat(b * Cb), S(h_pre, coef=sv['coef_h'], coff=b * Cb, act=RELU), M=Cb, K=Cb,
                                      KT=k, dil=d, stride=s, pad=pad))
-        dgam, dbet, dbias = P.bn_in[b].bwd(hp, b * Cb, cnt1, sv['save_h'], b * Cb, training, coefb_h, b * Cb, True)
-        G['bn_in'].append((dgam, dbet))
-        dbin.append(dbias)
     hp = ops.maxpool_bwd(gcat(nb * Cb), S(h_pre, coef=sv['coef_h'], coff=nb * Cb, act=RELU), sv['save_h'], Cb, s, dh,
                          nb * Cb)
     dgam, dbet, dbias = P.bn_in[nb].bwd(hp, nb * Cb, cnt1, sv['save_h'], nb * Cb, training, coefb_h, nb * Cb, True)
     G['bn_in'].append((dgam, dbet))
     dbin.append(dbias)
+    for ev in marks:
+        fk.wait(ev)                                    # the other branches' slices of dh / coefb_h
     G['bin'] = torch.cat(dbin)
     gs = S(g)
     gyh = S(dh, h_pre, coefb_h)
