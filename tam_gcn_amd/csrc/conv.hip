@@ -1678,8 +1678,8 @@ extern "C" int tamgcn_wgrad_max_split(const tamgcn_wgrad_desc* d) {
     if (!d || d->N <= 0 || d->T_out <= 0 || d->V <= 0) return -1;
     int wmt, wkt;
     if (!wgrad_glds_plan(d, &wmt, &wkt)) {
-        // register-staged kernel: frame chunks hold at most 8 frames; keep >= 2 of those chunks per workgroup
-        const long long m = (long long)d->N * ((d->T_out + 7) / 8) / 2;
+        // register-staged kernel: frame chunks hold at most 8 frames; at least one of those chunks per workgroup
+        const long long m = (long long)d->N * ((d->T_out + 7) / 8);
         return (int)(m < d->N ? d->N : (m > 65535 ? 65535 : m));
     }
     const long long chunks = (long long)d->N * (((long long)d->T_out * d->V) / W_PC);
