@@ -80,10 +80,16 @@ if not only or 'ctrgc' in only:
         rep('ctrgc_fwd ' + nm, us, 4.0 * N * T * V * (Cin + Cout), fl)
         us = timeit(lambda: ops.ctrgc_fwd(S(x), pq, W3, B3, W4, B4, A, al, Cin, Cout, S_, R, stats=True, keep_x3=True))
         rep('ctrgc_fwd +x3 store ' + nm, us, 4.0 * N * T * V * (Cin + 4 * Cout), fl)
+        # the training configuration: E built once per layer, forward loads its tiles and keeps x3
+        us = timeit(lambda: ops.ctrgc_build_E(S(x), pq, W3, B3, W4, B4, A, al, Cin, Cout, S_, R))
+        rep('ctrgc_build_e ' + nm, us, 4.0 * N * S_ * Cout * V * V, N * S_ * 2.0 * R * Cout * V * V)
+        Eg = ops.ctrgc_build_E(S(x), pq, W3, B3, W4, B4, A, al, Cin, Cout, S_, R)
+        us = timeit(lambda: ops.ctrgc_fwd(S(x), pq, W3, B3, W4, B4, A, al, Cin, Cout, S_, R, stats=True, keep_x3=True, E=Eg))
+        rep('ctrgc_fwd (E loaded, x3 kept; SURVEY bytes) ' + nm[:14], us, 4.0 * N * T * V * (Cin + Cout), fl)
         _, _, x3 = ops.ctrgc_fwd(S(x), pq, W3, B3, W4, B4, A, al, Cin, Cout, S_, R, stats=True, keep_x3=True)
         dy = r(N, Cout, T, V); ypre = r(N, Cout, T, V); cb = r(3, Cout)
         ca = (S(x), pq, W3, B3, W4, B4, A, al, Cin, Cout, S_, R, S(dy, ypre, cb))
-        us = timeit(lambda: ops.ctrgc_bwd_dx3(*ca))
+        us = timeit(lambda: ops.ctrgc_bwd_dx3(*ca, E=Eg))
         rep('ctrgc_bwd_dx3 ' + nm, us, 4.0 * N * T * V * (2 * Cout + 3 * Cout), N * S_ * (2.0 * R * Cout * V * V + 2.0 * Cout * T * V * V))
         us = timeit(lambda: ops.ctrgc_bwd_de(*ca))
         rep('ctrgc_bwd_de recompute ' + nm, us, 4.0 * N * T * V * (Cin + 2 * Cout), fl)
