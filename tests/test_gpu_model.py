@@ -113,3 +113,34 @@ def test_model_parity(case, golden_models):
         with torch.no_grad():
             l3 = m(x3).cpu().numpy()
         assert np.abs(l3 - gold[f'{tag}/logits_eval_3d']).max() <= 1e-3
+
+
+def test_ntu_full_length_against_oracle():
+    """BASELINE config 3 at its real clip length: NTU-RGB+D graph, 25 joints, 300 frames, 2 persons (one clip; the CPU
+    oracle needs a few seconds).  Train-mode logits, loss and the fc / data_bn gradients (eval mode is pinned by the golden model cases: with this
+    test's arbitrary running statistics it is ill-conditioned, logits ~1e5)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import ctrgcn_oracle as O
+    margs = dict(num_class=60, num_point=25, num_person=2, graph='graph.ntu_rgb_d.Graph', graph_args=dict(labeling_mode='spatial'))
+    shape = (1, 3, 300, 25, 2)
+    dev = torch.device('cuda:0')
+    m = M.Model(**margs)
+    fill_state_(m.state_dict(), seed=MODEL_PARAM_SEED)
+    x = make_input(shape, seed=MODEL_X_SEED)
+    lab = make_labels(shape[0], 60, seed=MODEL_LABEL_SEED)
+    sd = O.clone_state(m.state_dict(), requires_grad=True)            # CPU oracle on the same parameters
+    ref = O.model_forward(x, sd, 25, training=True)
+    torch.nn.functional.cross_entropy(ref, lab).backward()
+    m = m.to(dev).train()
+    out = m(x.to(dev))
+    loss = torch.nn.functional.cross_entropy(out, lab.to(dev))
+    loss.backward()
+    assert (out.detach().cpu() - ref.detach()).abs().max() <= 1e-3
+    assert torch.equal(out.argmax(1).cpu(), ref.argmax(1))
+    for k in ('fc.weight', 'fc.bias'):                                  # depend on the forward features only
+        g, r = dict(m.named_parameters())[k].grad.cpu(), sd[k].grad
+        assert (g - r).abs().max() <= 2e-3 * r.abs().max() + 1e-6, k
+    g, r = m.data_bn.weight.grad.cpu().double(), sd['data_bn.weight'].grad.double()   # through all ten blocks: flip-robust bar
+    assert float((g - r).norm() / r.norm()) <= 5e-2 and float((g * r).sum() / (g.norm() * r.norm())) >= 0.999
