@@ -325,7 +325,11 @@ __device__ void x3_chunk(const CtrgcArgs& a, int n, int c0, int t0, int bt, floa
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kq = lane >> 4;
     const int ncols = bt * V;
-    const int cw0 = wave * CW;
+    // Column tiles per wave.  Waves w and w + 4 share a SIMD (its MFMA pipe): with 20 tiles on 8 waves, "3 per wave in
+    // order" loads the four SIMDs 6/6/5/3; give every SIMD 5 instead -- wave w < 4 takes three, wave w + 4 two.
+    constexpr bool BAL = (G::NW == 8 && G::NCT == 20);
+    const int cw0 = BAL ? 5 * (wave & 3) + (wave < 4 ? 0 : 3) : wave * CW;
+    const bool third = !BAL || wave < 4;               // wave-uniform: does tile c = 2 exist for this wave
     float* Bs = X3;                                   // [SBK][pitchB]
     float* As = X3 + SBK * a.pitchB;                  // [ST*16][SBKP]
 
@@ -336,7 +340,7 @@ __device__ void x3_chunk(const CtrgcArgs& a, int n, int c0, int t0, int bt, floa
         for (int c = 0; c < CW; ++c) acc[s][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
     int bcol[CW];
 #pragma unroll
-    for (int c = 0; c < CW; ++c) { int col = (cw0 + c) * 16 + j; bcol[c] = col < ncols ? col : 0; }
+    for (int c = 0; c < CW; ++c) { int col = (cw0 + c) * 16 + j; bcol[c] = (col < ncols && (c < 2 || third)) ? col : 0; }
 
     const long long cs = (long long)a.T * V;
     const long long xb = ((long long)n * a.x_ctot + a.x_coff) * cs + (long long)t0 * V;
@@ -411,9 +415,11 @@ __device__ void x3_chunk(const CtrgcArgs& a, int n, int c0, int t0, int bt, floa
 #pragma unroll
             for (int c = 0; c < CW; ++c) split_bf16x8(b0[c], b1[c], bh[c], bl[c]);
 #pragma unroll
-            for (int c = 0; c < CW; ++c)
+            for (int c = 0; c < CW; ++c) {
+                if (BAL && c == 2 && !third) continue;  // wave-uniform
 #pragma unroll
                 for (int s = 0; s < ST; ++s) acc[s][c] = mfma_split(ah[s], al[s], bh[c], bl[c], acc[s][c]);
+            }
         } else {
 #pragma unroll
             for (int k4 = 0; k4 < SBK / 4; ++k4) {
@@ -423,9 +429,13 @@ __device__ void x3_chunk(const CtrgcArgs& a, int n, int c0, int t0, int bt, floa
 #pragma unroll
                 for (int c = 0; c < CW; ++c) bv[c] = bt_[k4 * 4 * a.pitchB + bcol[c]];
 #pragma unroll
-                for (int c = 0; c < CW; ++c)
+                for (int c = 0; c < (BAL ? 2 : CW); ++c)
 #pragma unroll
                     for (int s = 0; s < ST; ++s) acc[s][c] = mfma16(av[s], bv[c], acc[s][c]);
+                if (BAL && third) {                     // wave-uniform branch around the third tile's MFMAs
+#pragma unroll
+                    for (int s = 0; s < ST; ++s) acc[s][2] = mfma16(av[s], bv[2], acc[s][2]);
+                }
             }
         }
     }
@@ -435,7 +445,7 @@ __device__ void x3_chunk(const CtrgcArgs& a, int n, int c0, int t0, int bt, floa
 #pragma unroll
         for (int c = 0; c < CW; ++c) {
             int col = (cw0 + c) * 16 + j;
-            if (col >= ncols) continue;
+            if (col >= ncols || (BAL && c == 2 && !third)) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 int cl = kq * 4 + r;

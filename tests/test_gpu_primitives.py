@@ -291,3 +291,31 @@ def test_elementwise_kernels():
         bp = ops.maxpool_bwd(S(cot.to(d)), src, hsave, C_, s, dd, 2)
         close(dd[:, 2:], hb.grad, 1e-5, 1e-6, f'maxpool bwd s={s}')
         close(bp[1, 2:].sum(-1), (hb.grad * (h.detach() - hsave[0].cpu()[None, :, None, None])).sum((0, 2, 3)), 1e-3, 1e-3)
+
+
+@pytest.mark.parametrize('mode,bar', [('0', 2e-6), ('1', 3e-5)])
+def test_split_fp32_modes_against_fp64(mode, bar):
+    """TAMGCN_SPLIT_BF16 is read once per process: run the GEMM kernels in a child process per mode and bound their
+    error against an fp64 reference.  0 = exact fp32-input MFMA (rounding noise only); 1 = split-fp32 on the bf16 matrix
+    cores in the weight-gradient and wide data-gradient GEMMs (~4.5e-6), forward GEMMs exact in both."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TAMGCN_SPLIT_BF16=mode)
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'split_accuracy.py')], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    errs = {}
+    for line in out.stdout.splitlines():
+        m = re.match(r'\s+(wgrad|conv fwd|conv bwd-data|x3 \(kept\)|y)\s+max\|err\|/max\|ref\| ([0-9.e+-]+)', line)
+        if m:
+            errs.setdefault(m.group(1), []).append(float(m.group(2)))
+    assert set(errs) == {'wgrad', 'conv fwd', 'conv bwd-data', 'x3 (kept)', 'y'}, out.stdout[-2000:]
+    for k in ('conv fwd', 'x3 (kept)', 'y'):                     # activations: exact fp32 in every default mode
+        assert max(errs[k]) <= 2e-6, (k, errs[k])
+    for k in ('wgrad', 'conv bwd-data'):
+        assert max(errs[k]) <= bar, (k, errs[k])
+    if mode == '1':                                              # and the split really is in use where it should be
+        assert max(errs['wgrad']) > 1e-6
