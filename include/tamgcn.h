@@ -121,6 +121,16 @@ typedef struct tamgcn_wgrad_desc {
 int tamgcn_wgrad_max_split(const tamgcn_wgrad_desc* d);
 int tamgcn_wgrad(const tamgcn_wgrad_desc* d, void* stream);
 
+/* Several slab reductions in ONE launch (a layer's backward produces ~25 of them): for each descriptor
+ * out[e] (+)= scale * sum_s part[s*stride_s + e], fp64 accumulation in a fixed order. */
+typedef struct tamgcn_reduce_desc {
+    const float* part; float* out;
+    int nsplit, accumulate;
+    long long stride_s, count;
+    float scale;
+} tamgcn_reduce_desc;
+int tamgcn_reduce_multi(const tamgcn_reduce_desc* descs, int n, void* stream);
+
 /* out[e] = (accumulate ? out[e] : 0) + scale * sum_{s<nsplit} part[s*stride_s + e]
  * (fp64 accumulation, fixed order).  `part` is scratch: for nsplit > 128 it is reduced in place first. */
 int tamgcn_reduce_sum(float* part, int nsplit, long long stride_s, long long count,

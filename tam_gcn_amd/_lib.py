@@ -38,6 +38,11 @@ class WgradDesc(C.Structure):
                 ('part', C.c_void_p), ('nsplit', C.c_int)]
 
 
+class ReduceDesc(C.Structure):
+    _fields_ = [('part', C.c_void_p), ('out', C.c_void_p), ('nsplit', C.c_int), ('accumulate', C.c_int),
+                ('stride_s', C.c_longlong), ('count', C.c_longlong), ('scale', C.c_float)]
+
+
 class CtrgcDesc(C.Structure):
     _fields_ = [('N', C.c_int), ('Cin', C.c_int), ('Cout', C.c_int), ('S', C.c_int), ('R', C.c_int),
                 ('T', C.c_int), ('V', C.c_int),
@@ -58,6 +63,7 @@ SIGNATURES = {
     'tamgcn_conv': (_i, [C.POINTER(ConvDesc), _p]),
     'tamgcn_wgrad_max_split': (_i, [C.POINTER(WgradDesc)]),
     'tamgcn_wgrad': (_i, [C.POINTER(WgradDesc), _p]),
+    'tamgcn_reduce_multi': (_i, [C.POINTER(ReduceDesc), _i, _p]),
     'tamgcn_reduce_sum': (_i, [_p, _i, _ll, _ll, _f, _i, _p, _p]),
     'tamgcn_bn_fwd_finalize': (_i, [_p, _i, _i, _i, _d, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _i, _i, _i, _p]),
     'tamgcn_bn_bwd_finalize': (_i, [_p, _i, _i, _i, _d, _p, _p, _i, _i, _i, _p, _p, _p, _p, _i, _i, _i, _p]),

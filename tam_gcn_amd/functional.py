@@ -170,7 +170,13 @@ def gcn_forward(x, P, training, save):
 
 
 def gcn_backward(P, sv, dg, need_dx=True, extra_dx=None):
-    """Returns (dx, grads) with grads keyed like GcnParams' tensors."""
+    """Returns (dx, grads) with grads keyed like GcnParams' tensors.  All partial-slab reductions of the weight and
+    parameter gradients are deferred into ONE launch after the side streams have joined (ops.ReduceBatch)."""
+    with ops.ReduceBatch():
+        return _gcn_backward(P, sv, dg, need_dx, extra_dx)
+
+
+def _gcn_backward(P, sv, dg, need_dx=True, extra_dx=None):
     x, xbar, pq, y_pre, d_pre, o_pre, g = sv['x'], sv['xbar'], sv['pq'], sv['y_pre'], sv['d_pre'], sv['o_pre'], sv['g']
     training = sv['training']
     N, Cin, T, V = x.shape
@@ -307,6 +313,11 @@ def tcn_forward(g, P, training, save, xres=None):
 
 
 def tcn_backward(P, sv, dout, need_dg=True, need_dxres=True):
+    with ops.ReduceBatch():                            # one launch for every slab reduction of this backward
+        return _tcn_backward(P, sv, dout, need_dg, need_dxres)
+
+
+def _tcn_backward(P, sv, dout, need_dg=True, need_dxres=True):
     """Returns (dg, dxres, grads).  dxres is None for rmode 'zero'; for 'identity' it is the
     masked upstream gradient itself (caller adds it)."""
     g, xres, h_pre, cat_pre, r_pre, out = sv['g'], sv['xres'], sv['h_pre'], sv['cat_pre'], sv['r_pre'], sv['out']

@@ -7,7 +7,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import Src, ConvDesc, WgradDesc, CtrgcDesc
+from ._lib import Src, ConvDesc, WgradDesc, CtrgcDesc, ReduceDesc
 
 RELU = 1
 
@@ -121,11 +121,37 @@ def wgrad(gy, src, M, K, KT=1, dil=1, stride=1, pad=0):
     return reduce_sum(part, nsplit).view(M, K, KT, 1)
 
 
+class ReduceBatch:
+    """with ReduceBatch(): every reduce_sum() inside only registers its slabs and returns the (not yet filled) output;
+    ONE tamgcn_reduce_multi launch on the stream current at exit fills them all.  The caller guarantees that nothing
+    inside reads a reduced value and that every producer has been joined into that stream before the exit."""
+    _active = None
+
+    def __enter__(self):
+        self.items, self.prev = [], ReduceBatch._active
+        ReduceBatch._active = self
+        return self
+
+    def __exit__(self, *exc):
+        ReduceBatch._active = self.prev
+        if self.items and exc[0] is None:
+            arr = (ReduceDesc * len(self.items))()
+            for i, (part, nsplit, count, scale, acc, out) in enumerate(self.items):
+                arr[i] = ReduceDesc(_ptr(part), _ptr(out), nsplit, int(acc), count, count, scale)
+            _lib.check(_lib_().tamgcn_reduce_multi(arr, len(self.items), _stream()), 'tamgcn_reduce_multi')
+        self.items = []
+        return False
+
+
 def reduce_sum(part, nsplit, scale=1.0, out=None, accumulate=False):
-    """part [nsplit][...] -> sum over the leading dim."""
+    """part [nsplit][...] -> sum over the leading dim (deferred to the enclosing ReduceBatch, if any)."""
     count = part.numel() // nsplit
     if out is None:
         out = torch.empty(part.shape[1:], device=part.device, dtype=torch.float32)
+    rb = ReduceBatch._active
+    if rb is not None:
+        rb.items.append((part, nsplit, count, scale, accumulate, out))     # keeps `part` alive until the launch
+        return out
     _lib.check(_lib_().tamgcn_reduce_sum(_ptr(part), nsplit, count, count, scale, int(accumulate), _ptr(out), _stream()),
                'tamgcn_reduce_sum')
     return out
