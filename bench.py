@@ -247,7 +247,7 @@ def main():
         dist.init_process_group('nccl', device_id=dev)
 
     from tam_gcn_amd import _lib
-    from tam_gcn_amd.distributed import FlatGradBucket, SGDNesterov, broadcast_state
+    from tam_gcn_amd.distributed import FlatGradBucket, ParamArena, SGDNesterov, broadcast_state
     from tam_gcn_amd.models.ctrgcn import Model
     probe = _Probe(_lib.load())
     _lib._lib = probe                                     # every ABI launch goes through the probe
@@ -256,9 +256,10 @@ def main():
     model = Model(**MODEL_ARGS)
     dedegenerate_(model)
     model = model.to(dev).train()
+    arena = ParamArena(model)                             # parameters in one flat buffer: zero-copy operand packing, flat SGD
     broadcast_state(model)
-    bucket = FlatGradBucket(model.parameters())
-    opt = SGDNesterov(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    bucket = arena.grad_bucket()
+    opt = SGDNesterov(arena.params, lr=0.01, momentum=0.9, weight_decay=1e-4, arena=arena, bucket=bucket)
     g = torch.Generator().manual_seed(1234 + rank)
     B = args.batch
     x = (torch.rand(B, 3, T_FRAMES, V_JOINTS, 1, generator=g) * 2 - 1).to(dev)

@@ -10,6 +10,70 @@ import torch
 import torch.distributed as dist
 
 
+class ParamArena:
+    """All trainable parameters in ONE flat fp32 buffer; every ``p.data`` becomes a view of it (values preserved).
+
+    Two things follow.  (1) Modules that feed several parameters to one kernel as a concatenated operand (the three
+    subsets' conv3 weights, the temporal branches' entry convs, ...: ``_arena_groups()``) find them already back to
+    back: their per-forward ``torch.cat`` becomes a zero-copy view (60 launches per step).  (2) With a FlatGradBucket in
+    the same order the optimiser is four element-wise kernels on two flat buffers instead of ~40 multi-tensor launches.
+    Build it AFTER the model is on its device (``.to()`` re-allocates parameters and would orphan the arena), before
+    graph capture.  ``state_dict()`` keeps returning per-parameter tensors (cloned, so a checkpoint does not drag the
+    whole arena along); ``load_state_dict`` copies in place as usual."""
+
+    ALIGN = 16                      # floats: every group / stand-alone parameter starts on a 64-byte boundary (the kernels
+    #                                 take 16-byte vector and LDS-DMA paths only for 16-byte aligned operands)
+
+    def __init__(self, model):
+        seen, order, starts = set(), [], []          # starts[i]: parameter i opens a new aligned run
+        for m in model.modules():
+            if hasattr(m, '_arena_groups'):
+                for grp in m._arena_groups():
+                    first = True
+                    for p in grp:
+                        if p.requires_grad and id(p) not in seen:
+                            seen.add(id(p)); order.append(p); starts.append(first)
+                            first = False
+        for p in model.parameters():
+            if p.requires_grad and id(p) not in seen:
+                seen.add(id(p)); order.append(p); starts.append(True)
+        if not order:
+            raise ValueError('no trainable parameters')
+        dev, dt = order[0].device, order[0].dtype
+        if any(p.device != dev or p.dtype != dt for p in order):
+            raise ValueError('ParamArena needs all parameters on one device with one dtype')
+        self.params, self.offsets = order, []
+        off = 0
+        for p, st in zip(order, starts):
+            if st:
+                off = (off + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+            self.offsets.append(off)
+            off += p.numel()
+        self.total = (off + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.flat = torch.zeros(self.total, device=dev, dtype=dt)
+        with torch.no_grad():
+            for p, o in zip(order, self.offsets):
+                v = self.flat[o:o + p.numel()].view(p.shape)
+                v.copy_(p.data)
+                p.data = v
+        ptr = self.flat.untyped_storage().data_ptr()
+
+        def clone_views(module, state, prefix, meta):
+            for k, v in list(state.items()):
+                if isinstance(v, torch.Tensor) and v.untyped_storage().data_ptr() == ptr:
+                    state[k] = v.clone()
+        self._hook = model._register_state_dict_hook(clone_views)
+
+    def intact(self):
+        """False once something (``model.to``, manual re-assignment) has detached the parameters from the arena."""
+        base = self.flat.data_ptr()
+        return all(p.data_ptr() == base + o * p.element_size() for p, o in zip(self.params, self.offsets))
+
+    def grad_bucket(self):
+        """A FlatGradBucket with this arena's layout (same offsets, padding included): flat SGD needs them congruent."""
+        return FlatGradBucket(self.params, offsets=self.offsets, total=self.total)
+
+
 class FlatGradBucket:
     """All gradients in ONE flat fp32 buffer => one all-reduce, no per-tensor collectives.
 
@@ -18,18 +82,20 @@ class FlatGradBucket:
     gathers them into the bucket with one multi-tensor copy and re-points ``p.grad`` at the
     bucket's views, which is what the optimiser then reads."""
 
-    def __init__(self, params):
+    def __init__(self, params, offsets=None, total=None):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError('no trainable parameters')
         dev, dt = self.params[0].device, self.params[0].dtype
-        n = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(n, device=dev, dtype=dt)
-        self.views = []
-        off = 0
-        for p in self.params:
-            self.views.append(self.flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
+        if offsets is None:
+            offsets, off = [], 0
+            for p in self.params:
+                offsets.append(off)
+                off += p.numel()
+            total = off
+        self.offsets = list(offsets)
+        self.flat = torch.zeros(total, device=dev, dtype=dt)
+        self.views = [self.flat[o:o + p.numel()].view_as(p) for p, o in zip(self.params, self.offsets)]
 
     def zero(self):
         for p in self.params:
@@ -76,13 +142,30 @@ class SGDNesterov:
     """The reference's optimiser recipe (processor/recognition_rgb.py:23-28: SGD, momentum 0.9,
     nesterov, weight decay) as capture-safe multi-tensor updates on the bucket's views."""
 
-    def __init__(self, params, lr=0.1, momentum=0.9, weight_decay=1e-4):
+    def __init__(self, params, lr=0.1, momentum=0.9, weight_decay=1e-4, arena=None, bucket=None):
+        """With ``arena`` and a ``bucket`` built over ``arena.params`` the update runs on the two flat buffers."""
         self.params = [p for p in params if p.requires_grad]
         self.lr, self.momentum, self.wd = lr, momentum, weight_decay
-        self.bufs = [torch.zeros_like(p) for p in self.params]
+        self.arena, self.bucket = None, None
+        if arena is not None and bucket is not None:
+            if [id(p) for p in arena.params] != [id(p) for p in bucket.params] or list(arena.offsets) != list(bucket.offsets):
+                raise ValueError('SGDNesterov: build the bucket with arena.grad_bucket() (same order and offsets)')
+            if not arena.intact():
+                raise ValueError('SGDNesterov: the ParamArena no longer backs the parameters')
+            self.arena, self.bucket = arena, bucket
+            self.flat_buf = torch.zeros_like(arena.flat)
+        else:
+            self.bufs = [torch.zeros_like(p) for p in self.params]
 
     @torch.no_grad()
     def step(self):
+        if self.arena is not None:
+            p, g, buf = self.arena.flat, self.bucket.flat, self.flat_buf
+            d = torch.add(g, p, alpha=self.wd)                          # g + wd * p
+            buf.mul_(self.momentum).add_(d)                             # buf = m*buf + d
+            d.add_(buf, alpha=self.momentum)                            # d + m*buf (nesterov)
+            p.add_(d, alpha=-self.lr)
+            return
         grads = [p.grad for p in self.params]
         d = torch._foreach_add(grads, self.params, alpha=self.wd)      # g + wd * p
         torch._foreach_mul_(self.bufs, self.momentum)

@@ -81,6 +81,25 @@ def _w2(conv):
     return w.reshape(w.shape[0], -1)
 
 
+def _cat(ts, stack=False):
+    """torch.cat / torch.stack of the tensors -- without a copy when they already sit back to back in memory, which is
+    how tam_gcn_amd.distributed.ParamArena lays the packed groups out (60 concatenation kernels per step otherwise)."""
+    t0 = ts[0]
+    ptr, ok = t0.data_ptr(), True
+    for t in ts:
+        if not t.is_contiguous() or t.data_ptr() != ptr or t.dtype != t0.dtype:
+            ok = False
+            break
+        ptr += t.numel() * t.element_size()
+    if not ok:
+        return torch.stack(ts) if stack else torch.cat(ts)
+    shape = (len(ts),) + tuple(t0.shape) if stack else (sum(t.shape[0] for t in ts),) + tuple(t0.shape[1:])
+    n = 1
+    for d in shape:
+        n *= d
+    return torch.as_strided(t0, (n,), (1,)).view(shape)      # same storage: the arena
+
+
 def _require_hip(x):
     if not x.is_cuda:
         raise RuntimeError('tam_gcn_amd: the CTR-GCN hot path runs on MI355X only (got a CPU tensor); '
@@ -176,6 +195,12 @@ class MultiScale_TemporalConv(nn.Module):
             t += [r.conv.weight, r.conv.bias, r.bn.weight, r.bn.bias]
         return t
 
+    def _arena_groups(self):
+        """Parameter lists _pack() concatenates, in that order (ParamArena keeps each back to back)."""
+        nb = len(self._dils)
+        heads = [self.branches[b][0] for b in range(nb + 1)]
+        return [[h.weight for h in heads], [h.bias for h in heads]]
+
     def _pack(self, params, ext_res=None, relu=False):
         """params in _tensors() order (+ 4 tensors of an external unit_tcn residual)."""
         nb = len(self._dils)
@@ -195,7 +220,7 @@ class MultiScale_TemporalConv(nn.Module):
         P.bn_in.append(Fn.BN(self.branches[nb][1])); P.bn_pool = Fn.BN(self.branches[nb][4])
         w, bia, _, _ = (next(it) for _ in range(4))
         P.Wl, P.bl, P.bn_l = w, bia, Fn.BN(self.branches[nb + 1][1])
-        P.Win, P.bin = torch.cat(wins), torch.cat(bins)
+        P.Win, P.bin = _cat(wins), _cat(bins)
         P.Wr = P.br = P.bnr = None
         P.rk = 1
         if ext_res is not None:                       # TCN_GCN_unit's own residual
@@ -323,6 +348,12 @@ class unit_gcn(nn.Module):
         t += [self.offset_conv[0].weight, self.offset_conv[0].bias, self.offset_conv[1].weight, self.offset_conv[1].bias]
         return t
 
+    def _arena_groups(self):
+        """Parameter lists _pack() concatenates, in that order (ParamArena keeps each back to back)."""
+        cs = self.convs
+        return [[w for c in cs for w in (c.conv1.weight, c.conv2.weight)], [b for c in cs for b in (c.conv1.bias, c.conv2.bias)],
+                [c.conv3.weight for c in cs], [c.conv3.bias for c in cs], [c.conv4.weight for c in cs], [c.conv4.bias for c in cs]]
+
     def _pack(self, params):
         P = Fn.GcnParams()
         S_, Cin, Cout = self.num_subset, self.in_c, self.out_c
@@ -334,9 +365,9 @@ class unit_gcn(nn.Module):
             w1, b1, w2, b2, w3_, b3_, w4_, b4_ = params[2 + 8 * i: 10 + 8 * i]
             w12 += [_w2(w1), _w2(w2)]; b12 += [b1, b2]
             w3.append(_w2(w3_)); b3.append(b3_); w4.append(_w2(w4_)); b4.append(b4_)
-        P.W12, P.B12 = torch.cat(w12), torch.cat(b12)
-        P.W3, P.B3 = torch.cat(w3), torch.cat(b3)
-        P.W4, P.B4 = torch.stack(w4), torch.stack(b4)
+        P.W12, P.B12 = _cat(w12), _cat(b12)
+        P.W3, P.B3 = _cat(w3), _cat(b3)
+        P.W4, P.B4 = _cat(w4, stack=True), _cat(b4, stack=True)
         k = 2 + 8 * S_
         P.bn = Fn.BN(self.bn)
         k += 2

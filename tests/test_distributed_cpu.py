@@ -66,3 +66,51 @@ def test_shard_batch_covers_everything():
         spans = [shard_batch(n, r, w) for r in range(w)]
         assert spans[0][0] == 0 and spans[-1][1] == n
         assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+
+
+def test_param_arena_zero_copy_packing_and_flat_sgd():
+    """ParamArena: values preserved, packed operands become views of the arena, state_dict stays per-parameter, and
+    the flat optimiser step equals the multi-tensor one."""
+    import copy
+    from tam_gcn_amd.distributed import ParamArena
+    from tam_gcn_amd.models.ctrgcn import Model
+    torch.manual_seed(3)
+    m = Model(num_class=10, num_point=20, num_person=1, graph='graph.ucla.Graph', graph_args=dict(labeling_mode='spatial'))
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(0.01 * torch.randn_like(p))
+    ref = copy.deepcopy(m)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    arena = ParamArena(m)
+    assert arena.intact() and arena.flat.numel() >= sum(p.numel() for p in m.parameters())
+    assert all(p.data_ptr() % 16 == 0 for grp in m.l5.gcn1._arena_groups() for p in grp[:1])       # aligned group starts
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k]), k
+        assert v.untyped_storage().data_ptr() != arena.flat.untyped_storage().data_ptr(), k      # cloned, not a view
+    gcn, tcn = m.l5.gcn1, m.l5.tcn1
+    P = gcn._pack(gcn._tensors(torch.device('cpu')))
+    assert P.W3.data_ptr() == gcn.convs[0].conv3.weight.data_ptr() and P.W12.data_ptr() == gcn.convs[0].conv1.weight.data_ptr()
+    assert torch.equal(P.W3, torch.cat([c.conv3.weight.reshape(gcn.out_c, -1) for c in gcn.convs]))
+    assert torch.equal(P.W4, torch.stack([c.conv4.weight.reshape(gcn.out_c, -1) for c in gcn.convs]))
+    assert torch.equal(P.B12, torch.cat([b for c in gcn.convs for b in (c.conv1.bias, c.conv2.bias)]))
+    Pt = tcn._pack(tcn._tensors())
+    assert Pt.Win.data_ptr() == tcn.branches[0][0].weight.data_ptr()
+    Pr = ref.l5.gcn1._pack(ref.l5.gcn1._tensors(torch.device('cpu')))                          # no arena: plain cat, same values
+    assert torch.equal(Pr.W3, P.W3) and Pr.W3.data_ptr() != ref.l5.gcn1.convs[0].conv3.weight.data_ptr()
+    # one optimiser step, flat vs multi-tensor, same gradients
+    bucket = arena.grad_bucket()
+    opt = SGDNesterov(arena.params, lr=0.1, momentum=0.9, weight_decay=1e-4, arena=arena, bucket=bucket)
+    rparams = dict(ref.named_parameters())
+    rlist = [rparams[k] for k, _ in m.named_parameters()]
+    ropt = SGDNesterov(rlist, lr=0.1, momentum=0.9, weight_decay=1e-4)
+    g = torch.Generator().manual_seed(5)
+    for _ in range(2):
+        for (k, p), rp in zip(m.named_parameters(), rlist):
+            gr = torch.randn(p.shape, generator=g)
+            p.grad = gr.clone(); rp.grad = gr.clone()
+        bucket.pack(); opt.step(); ropt.step()
+    for (k, p), rp in zip(m.named_parameters(), rlist):
+        assert torch.allclose(p, rp, rtol=1e-6, atol=1e-7), k
+    assert arena.intact()
+    m.load_state_dict(before)                                    # in-place copies keep the views
+    assert arena.intact() and torch.equal(m.fc.weight, before['fc.weight'])
