@@ -45,3 +45,30 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
     with pytest.raises(_lib.TamgcnLibraryError, match='no CPU fallback'):
         _lib.load()
+
+
+def test_abi_rejects_bad_arguments_without_touching_the_gpu():
+    """Argument checks run before any HIP call: they can be exercised on a machine without a GPU.  Every entry point
+    returns a negative status and leaves a message in tamgcn_last_error(); unsupported geometries are refused, not mis-run."""
+    import ctypes as C
+    from tam_gcn_amd import build, _lib
+    build.build()
+    lib = C.CDLL(_lib.LIB_PATH)
+    lib.tamgcn_last_error.restype = C.c_char_p
+    for fn, args in [('tamgcn_conv', (None, None)), ('tamgcn_wgrad', (None, None)),
+                     ('tamgcn_ctrgc_fwd', (None, None, None, None, None)), ('tamgcn_reduce_multi', (None, 0, None)),
+                     ('tamgcn_ctrgc_build_e', (None, None, None))]:
+        rc = getattr(lib, fn)(*args)
+        assert rc < 0, fn
+        assert fn.encode() in lib.tamgcn_last_error(), (fn, lib.tamgcn_last_error())
+    assert lib.tamgcn_conv_nparts(None) == -1 and lib.tamgcn_wgrad_max_split(None) == -1
+    assert lib.tamgcn_ctrgc_lds_bytes(3, 20, 8) > 64 * 1024          # N-UCLA tiles: LDS resident
+    assert lib.tamgcn_ctrgc_lds_bytes(3, 25, 8) > 0                  # NTU
+    assert lib.tamgcn_ctrgc_lds_bytes(3, 64, 32) == -1               # V = 64: no LDS-resident tiling (DESIGN.md, known gap)
+    assert lib.tamgcn_ctrgc_lds_bytes(2, 20, 8) == -1                # subsets: 1 or 3
+    # a descriptor with impossible sizes is refused with its own message
+    d = _lib.ConvDesc()
+    d.N, d.K, d.M, d.T_in, d.T_out, d.V, d.KT = 0, 4, 4, 4, 4, 20, 1
+    one = C.c_float(0.0)
+    d.src.x1 = C.addressof(one); d.w = C.addressof(one); d.y = C.addressof(one)
+    assert lib.tamgcn_conv(C.byref(d), None) < 0 and b'bad dims' in lib.tamgcn_last_error()
