@@ -265,6 +265,22 @@ int tamgcn_add_act_bwd(const float* dout, const float* out, int relu, const floa
 /* y = prologue value (materialise a src; used by stand-alone modules and tests) */
 int tamgcn_apply(const tamgcn_src* src, int N, int C, int T, int V, float* y, int yctot, int ycoff, void* stream);
 
+/* ---- stem and head of models.ctrgcn.Model (reference models/ctrgcn.py:328-332, 343-348) -------------------------
+ * stem: x (N, C, T, V, M) -> data_bn over channel j = (m*V + v)*C + c with statistics over (n, t) -> (N*M, C, T, V).
+ *   _stem_stats  part [2][J][N], J = C*V*M: (sum a, sum a*(b - center[j])) over t; forward a = b = x, center NULL (moments
+ *                for tamgcn_bn_fwd_finalize); backward a = dout (N*M, C, T, V), b = x, center = saved mean (for _bn_bwd_finalize)
+ *   _stem_apply  dout NULL: out (N*M, C, T, V) = c1[j]*x + c0[j];  dout given: out = dx (N, C, T, V, M) = c1*dout + c2*x + c0
+ * head: pooled (N, C) = mean over (m, t, v) of x10 (N*M, C, T, V); logits (N, K) = pooled W^T + b and their gradients. */
+int tamgcn_stem_stats(const float* x, const float* dout, const float* center, int N, int C, int T, int V, int M,
+                      float* part, void* stream);
+int tamgcn_stem_apply(const float* x, const float* dout, const float* coef, int N, int C, int T, int V, int M,
+                      float* out, void* stream);
+int tamgcn_head_pool_fwd(const float* x, int N, int C, int T, int V, int M, float* pooled, void* stream);
+int tamgcn_head_pool_bwd(const float* dpooled, int N, int C, int T, int V, int M, float* dx, void* stream);
+int tamgcn_head_fc_fwd(const float* pooled, const float* W, const float* b, int N, int C, int K, float* logits, void* stream);
+int tamgcn_head_fc_bwd(const float* dlogits, const float* pooled, const float* W, int N, int C, int K,
+                       float* dW, float* db, float* dpooled, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,6 +63,12 @@ SIGNATURES = {
     'tamgcn_conv': (_i, [C.POINTER(ConvDesc), _p]),
     'tamgcn_wgrad_max_split': (_i, [C.POINTER(WgradDesc)]),
     'tamgcn_wgrad': (_i, [C.POINTER(WgradDesc), _p]),
+    'tamgcn_stem_stats': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    'tamgcn_stem_apply': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    'tamgcn_head_pool_fwd': (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
+    'tamgcn_head_pool_bwd': (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
+    'tamgcn_head_fc_fwd': (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),
+    'tamgcn_head_fc_bwd': (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
     'tamgcn_reduce_multi': (_i, [C.POINTER(ReduceDesc), _i, _p]),
     'tamgcn_reduce_sum': (_i, [_p, _i, _ll, _ll, _f, _i, _p, _p]),
     'tamgcn_bn_fwd_finalize': (_i, [_p, _i, _i, _i, _d, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _i, _i, _i, _p]),

@@ -1,0 +1,173 @@
+// Stem and head of models.ctrgcn.Model: the input BatchNorm1d over (person, joint, channel)
+// with its two permutes (reference models/ctrgcn.py:328-332) and global mean-pool + fc (:343-348).
+// Tiny tensors (3-6 channels in, 256 x num_class out): the point is not bandwidth but that the model's forward /
+// backward no longer contains stock framework kernels or full-tensor permute copies.
+//
+//   stem   x (N, C, T, V, M) --data_bn over j = (m*V + v)*C + c, statistics over (n, t)--> (N*M, C, T, V)
+//   head   x10 (N*M, C, T, V) --mean over (m, t, v)--> pooled (N, C) --fc--> logits (N, K)
+#include "common.h"
+
+namespace {
+
+constexpr int SH_NT = 256;
+
+// part[stat][j][n]: stat 0 = sum a, stat 1 = sum a * (b - center[j]) over t   (forward: a = b = x, center = 0;
+// backward: a = dout, b = x, center = saved mean)
+__global__ __launch_bounds__(SH_NT) void stem_stats_kernel(const float* x, const float* dout, const float* center,
+                                                           int N, int C, int T, int V, int M, float* part) {
+    const int n = blockIdx.x, J = C * V * M, VM = V * M;
+    for (int i = threadIdx.x; i < J; i += SH_NT) {         // i in memory order (c, v, m)
+        const int c = i / VM, vm = i - c * VM, v = vm / M, m = vm - v * M;
+        const int j = (m * V + v) * C + c;
+        const float mu = center ? center[j] : 0.f;
+        const float* xp = x + ((long long)n * C + c) * T * VM + vm;
+        const float* dp = dout ? dout + (((long long)n * M + m) * C + c) * T * V + v : nullptr;
+        float s1 = 0.f, s2 = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const float b = xp[(long long)t * VM];
+            const float a = dp ? dp[(long long)t * V] : b;
+            s1 += a;
+            s2 = fmaf(a, b - mu, s2);
+        }
+        part[((long long)0 * J + j) * N + n] = s1;
+        part[((long long)1 * J + j) * N + n] = s2;
+    }
+}
+
+// forward: out[(n*M+m), c, t, v] = c1[j] x + c0[j];  backward: dx[n,c,t,v,m] = c1[j] dout + c2[j] x + c0[j]
+__global__ __launch_bounds__(SH_NT) void stem_apply_kernel(const float* x, const float* dout, const float* coef,
+                                                           int N, int C, int T, int V, int M, float* out, int backward) {
+    const long long total = (long long)N * C * T * V * M;
+    const int J = C * V * M;
+    for (long long e = (long long)blockIdx.x * SH_NT + threadIdx.x; e < total; e += (long long)gridDim.x * SH_NT) {
+        long long r = e;                                    // e indexes x: (n, c, t, v, m)
+        const int m = (int)(r % M); r /= M;
+        const int v = (int)(r % V); r /= V;
+        const int t = (int)(r % T); r /= T;
+        const int c = (int)(r % C);
+        const int n = (int)(r / C);
+        const int j = (m * V + v) * C + c;
+        const long long o = ((((long long)n * M + m) * C + c) * T + t) * V + v;   // (n*M+m, c, t, v)
+        if (!backward) out[o] = fmaf(coef[j], x[e], coef[2 * J + j]);
+        else out[e] = fmaf(coef[j], dout[o], fmaf(coef[J + j], x[e], coef[2 * J + j]));
+    }
+}
+
+// pooled[n][c] = mean over (m, t, v) of x[(n*M+m), c, t, v]; one wave per (n, c)
+__global__ __launch_bounds__(SH_NT) void pool_fwd_kernel(const float* x, int N, int C, int L, int M, float* pooled) {
+    const int row = blockIdx.x * (SH_NT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N * C) return;
+    const int n = row / C, c = row - n * C;
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) {
+        const float* p = x + (((long long)n * M + m) * C + c) * L;
+        for (int i = lane; i < L; i += 64) s += p[i];
+    }
+    s = wave_sum64(s);
+    if (lane == 0) pooled[row] = s / (float)(M * L);
+}
+
+// dx[(n*M+m), c, :, :] = dpooled[n][c] / (M*L)
+__global__ __launch_bounds__(SH_NT) void pool_bwd_kernel(const float* dpooled, int N, int C, int L, int M, float* dx) {
+    const int row = blockIdx.x, n = row / (M * C), c = row % C;       // row = (n*M+m)*C + c
+    const float v = dpooled[n * C + c] / (float)(M * L);
+    float* p = dx + (long long)row * L;
+    for (int i = threadIdx.x; i < L; i += SH_NT) p[i] = v;
+}
+
+// logits[n][k] = b[k] + sum_c pooled[n][c] W[k][c]; one workgroup per sample, a wave per class (round robin)
+__global__ __launch_bounds__(SH_NT) void fc_fwd_kernel(const float* pooled, const float* W, const float* b, int N, int C, int K, float* logits) {
+    const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = wave; k < K; k += SH_NT / 64) {
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s = fmaf(pooled[(long long)n * C + c], W[(long long)k * C + c], s);
+        s = wave_sum64(s);
+        if (lane == 0) logits[(long long)n * K + k] = s + (b ? b[k] : 0.f);
+    }
+}
+
+// blockIdx.x < K: dW[k][:] = sum_n dl[n][k] pooled[n][:], db[k] = sum_n dl[n][k];  blockIdx.x >= K: dpooled[n][:] = dl[n][:] W
+__global__ __launch_bounds__(SH_NT) void fc_bwd_kernel(const float* dl, const float* pooled, const float* W, int N, int C, int K,
+                                                       float* dW, float* db, float* dpooled) {
+    if ((int)blockIdx.x < K) {
+        const int k = blockIdx.x;
+        for (int c = threadIdx.x; c < C; c += SH_NT) {
+            float s = 0.f;
+            for (int n = 0; n < N; ++n) s = fmaf(dl[(long long)n * K + k], pooled[(long long)n * C + c], s);
+            dW[(long long)k * C + c] = s;
+        }
+        if (threadIdx.x == 0) {
+            float s = 0.f;
+            for (int n = 0; n < N; ++n) s += dl[(long long)n * K + k];
+            db[k] = s;
+        }
+    } else {
+        const int n = blockIdx.x - K;
+        for (int c = threadIdx.x; c < C; c += SH_NT) {
+            float s = 0.f;
+            for (int k = 0; k < K; ++k) s = fmaf(dl[(long long)n * K + k], W[(long long)k * C + c], s);
+            dpooled[(long long)n * C + c] = s;
+        }
+    }
+}
+
+}  // namespace
+
+static bool sh_dims_ok(int N, int C, int T, int V, int M) {
+    return N > 0 && C > 0 && T > 0 && V > 0 && M > 0 && (long long)N * C * T * V * M < (1LL << 40);
+}
+
+extern "C" int tamgcn_stem_stats(const float* x, const float* dout, const float* center, int N, int C, int T, int V, int M,
+                                 float* part, void* stream) {
+    TG_CHECK(x && part && sh_dims_ok(N, C, T, V, M) && (!dout || center), "tamgcn_stem_stats: bad args");
+    hipLaunchKernelGGL(stem_stats_kernel, dim3(N), dim3(SH_NT), 0, (hipStream_t)stream, x, dout, center, N, C, T, V, M, part);
+    tamgcn_note_kernel("stem_stats_kernel");
+    TG_LAUNCH_CHECK("tamgcn_stem_stats");
+    return 0;
+}
+
+extern "C" int tamgcn_stem_apply(const float* x, const float* dout, const float* coef, int N, int C, int T, int V, int M,
+                                 float* out, void* stream) {
+    TG_CHECK(x && coef && out && sh_dims_ok(N, C, T, V, M), "tamgcn_stem_apply: bad args");
+    const long long total = (long long)N * C * T * V * M;
+    long long blocks = (total + SH_NT - 1) / SH_NT;
+    if (blocks > 65535LL * 16) blocks = 65535LL * 16;
+    hipLaunchKernelGGL(stem_apply_kernel, dim3((unsigned)blocks), dim3(SH_NT), 0, (hipStream_t)stream, x, dout, coef, N, C, T, V, M, out,
+                       dout ? 1 : 0);
+    tamgcn_note_kernel("stem_apply_kernel");
+    TG_LAUNCH_CHECK("tamgcn_stem_apply");
+    return 0;
+}
+
+extern "C" int tamgcn_head_pool_fwd(const float* x, int N, int C, int T, int V, int M, float* pooled, void* stream) {
+    TG_CHECK(x && pooled && sh_dims_ok(N, C, T, V, M), "tamgcn_head_pool_fwd: bad args");
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3((unsigned)ceil_div(N * C, SH_NT / 64)), dim3(SH_NT), 0, (hipStream_t)stream, x, N, C, T * V, M, pooled);
+    tamgcn_note_kernel("pool_fwd_kernel");
+    TG_LAUNCH_CHECK("tamgcn_head_pool_fwd");
+    return 0;
+}
+
+extern "C" int tamgcn_head_pool_bwd(const float* dpooled, int N, int C, int T, int V, int M, float* dx, void* stream) {
+    TG_CHECK(dpooled && dx && sh_dims_ok(N, C, T, V, M), "tamgcn_head_pool_bwd: bad args");
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3((unsigned)(N * M * C)), dim3(SH_NT), 0, (hipStream_t)stream, dpooled, N, C, T * V, M, dx);
+    tamgcn_note_kernel("pool_bwd_kernel");
+    TG_LAUNCH_CHECK("tamgcn_head_pool_bwd");
+    return 0;
+}
+
+extern "C" int tamgcn_head_fc_fwd(const float* pooled, const float* W, const float* b, int N, int C, int K, float* logits, void* stream) {
+    TG_CHECK(pooled && W && logits && N > 0 && C > 0 && K > 0, "tamgcn_head_fc_fwd: bad args");
+    hipLaunchKernelGGL(fc_fwd_kernel, dim3(N), dim3(SH_NT), 0, (hipStream_t)stream, pooled, W, b, N, C, K, logits);
+    tamgcn_note_kernel("fc_fwd_kernel");
+    TG_LAUNCH_CHECK("tamgcn_head_fc_fwd");
+    return 0;
+}
+
+extern "C" int tamgcn_head_fc_bwd(const float* dlogits, const float* pooled, const float* W, int N, int C, int K,
+                                  float* dW, float* db, float* dpooled, void* stream) {
+    TG_CHECK(dlogits && pooled && W && dW && db && dpooled && N > 0 && C > 0 && K > 0, "tamgcn_head_fc_bwd: bad args");
+    hipLaunchKernelGGL(fc_bwd_kernel, dim3(K + N), dim3(SH_NT), 0, (hipStream_t)stream, dlogits, pooled, W, N, C, K, dW, db, dpooled);
+    tamgcn_note_kernel("fc_bwd_kernel");
+    TG_LAUNCH_CHECK("tamgcn_head_fc_bwd");
+    return 0;
+}

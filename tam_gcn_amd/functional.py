@@ -566,3 +566,60 @@ class ConvBNFn(torch.autograd.Function):
                 dx, _ = ops.conv(gy, K=M, w=w, bias=None, M=Cin, KT=k, dil=d, stride=1, pad=(k - 1) * d - pad,
                                  wmode=1, up=s, T_out=T)
         return None, dx, dw, dbias, dgam, dbet
+
+
+# ===========================================================================
+# stem (data_bn + permutes) and head (global mean-pool + fc) of Model  -- SURVEY.md §8 row f1
+# ===========================================================================
+class StemFn(torch.autograd.Function):
+    """x (N, C, T, V, M) -> data_bn (channels (m, v, c), statistics over (n, t)) -> (N*M, C, T, V)
+    (reference models/ctrgcn.py:328-332: two permute copies and a BatchNorm1d)."""
+
+    @staticmethod
+    def forward(ctx, bn_mod, x, w, b):
+        x = x.contiguous()
+        N, C_, T, V, M = x.shape
+        bn = BN(bn_mod)
+        J = C_ * V * M
+        if bn.C != J:
+            raise RuntimeError(f'tam_gcn_amd: data_bn has {bn.C} features, input gives {J}')
+        training = bn_mod.training
+        coef, save = torch.empty(3, J, device=x.device), torch.empty(2, J, device=x.device)
+        part = ops.stem_stats(x) if training else None
+        bn.fwd(part, 0, N * T, training, coef, save, 0)
+        out = ops.stem_apply(x, coef)
+        ctx.bn, ctx.training = bn, training
+        ctx.save_for_backward(x, save)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, save = ctx.saved_tensors
+        N, C_, T, V, M = x.shape
+        dout = dout.contiguous()
+        J = C_ * V * M
+        part = ops.stem_stats(x, dout, save[0].contiguous())
+        coefb = torch.empty(3, J, device=x.device)
+        dg, db, _ = ctx.bn.bwd(part, 0, N * T, save, 0, ctx.training, coefb, 0)
+        dx = ops.stem_apply(x, coefb, dout) if ctx.needs_input_grad[1] else None
+        return None, dx, dg, db
+
+
+class HeadFn(torch.autograd.Function):
+    """x10 (N*M, C, T, V) -> mean over (m, t, v) -> fc  (reference models/ctrgcn.py:343-348, drop_out = 0)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, M):
+        x = x.contiguous()
+        pooled = ops.head_pool_fwd(x, M)
+        logits = ops.head_fc_fwd(pooled, W, b)
+        ctx.M, ctx.TV = M, (x.shape[2], x.shape[3])
+        ctx.save_for_backward(pooled, W)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dl):
+        pooled, W = ctx.saved_tensors
+        dW, db, dpooled = ops.head_fc_bwd(dl.contiguous(), pooled, W)
+        dx = ops.head_pool_bwd(dpooled, ctx.M, *ctx.TV) if ctx.needs_input_grad[0] else None
+        return dx, dW, db, None

@@ -86,8 +86,9 @@ def _cat(ts, stack=False):
     how tam_gcn_amd.distributed.ParamArena lays the packed groups out (60 concatenation kernels per step otherwise)."""
     t0 = ts[0]
     ptr, ok = t0.data_ptr(), True
+    base = t0.untyped_storage().data_ptr()             # back to back is not enough: they must live in ONE storage
     for t in ts:
-        if not t.is_contiguous() or t.data_ptr() != ptr or t.dtype != t0.dtype:
+        if not t.is_contiguous() or t.data_ptr() != ptr or t.dtype != t0.dtype or t.untyped_storage().data_ptr() != base:
             ok = False
             break
         ptr += t.numel() * t.element_size()
@@ -467,17 +468,18 @@ class Model(nn.Module):
             N, T, VC = x.shape
             x = x.view(N, T, self.num_point, -1).permute(0, 3, 1, 2).contiguous().unsqueeze(-1)
         N, C, T, V, M = x.size()
-        x = x.permute(0, 4, 3, 1, 2).contiguous().view(N, M * V * C, T)
-        x = self.data_bn(x)
-        x = x.view(N, M, V, C, T).permute(0, 1, 3, 4, 2).contiguous().view(N * M, C, T, V)
+        # reference :330-332 (permute, BatchNorm1d, permute back) as one statistics pass + one apply-and-permute pass
+        x = Fn.StemFn.apply(self.data_bn, x, self.data_bn.weight, self.data_bn.bias)
         for i in range(1, 11):
             x = getattr(self, f'l{i}')(x)
         return x, N, M
 
     def forward(self, x):
         x, N, M = self._blocks(_require_hip(x))
-        x = x.view(N, M, x.size(1), -1).mean(3).mean(1)
-        return self.fc(self.drop_out(x))
+        if isinstance(self.drop_out, nn.Dropout):          # drop_out > 0: pool here, torch's dropout + linear (reference :343-348)
+            x = x.view(N, M, x.size(1), -1).mean(3).mean(1)
+            return self.fc(self.drop_out(x))
+        return Fn.HeadFn.apply(x, self.fc.weight, self.fc.bias, M)
 
     def extract_feature(self, x):
         x, N, M = self._blocks(_require_hip(x))

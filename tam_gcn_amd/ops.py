@@ -354,3 +354,52 @@ def apply(src, C_, y=None, ycoff=0):
     sc = src.c()
     _lib.check(_lib_().tamgcn_apply(C.byref(sc), N, C_, T, V, _ptr(y), y.shape[1], ycoff, _stream()), 'tamgcn_apply')
     return y
+
+
+# ---------------------------------------------------------------------------
+# stem / head of Model
+def stem_stats(x5, dout=None, center=None):
+    """x5 (N, C, T, V, M) -> partial sums [2][C*V*M][N] for the data_bn finalize (forward: moments; backward with dout)."""
+    N, C_, T, V, M = x5.shape
+    part = empty(2, C_ * V * M, N, like=x5)
+    _lib.check(_lib_().tamgcn_stem_stats(_ptr(x5), _ptr(dout), _ptr(center), N, C_, T, V, M, _ptr(part), _stream()), 'tamgcn_stem_stats')
+    return part
+
+
+def stem_apply(x5, coef, dout=None):
+    """forward: (N*M, C, T, V) = c1*x + c0 (permuted);  with dout: dx (N, C, T, V, M) = c1*dout + c2*x + c0."""
+    N, C_, T, V, M = x5.shape
+    out = empty(N * M, C_, T, V, like=x5) if dout is None else torch.empty_like(x5)
+    _lib.check(_lib_().tamgcn_stem_apply(_ptr(x5), _ptr(dout), _ptr(coef), N, C_, T, V, M, _ptr(out), _stream()), 'tamgcn_stem_apply')
+    return out
+
+
+def head_pool_fwd(x, M):
+    NM, C_, T, V = x.shape
+    pooled = empty(NM // M, C_, like=x)
+    _lib.check(_lib_().tamgcn_head_pool_fwd(_ptr(x), NM // M, C_, T, V, M, _ptr(pooled), _stream()), 'tamgcn_head_pool_fwd')
+    return pooled
+
+
+def head_pool_bwd(dpooled, M, T, V):
+    N, C_ = dpooled.shape
+    dx = empty(N * M, C_, T, V, like=dpooled)
+    _lib.check(_lib_().tamgcn_head_pool_bwd(_ptr(dpooled), N, C_, T, V, M, _ptr(dx), _stream()), 'tamgcn_head_pool_bwd')
+    return dx
+
+
+def head_fc_fwd(pooled, W, b):
+    N, C_ = pooled.shape
+    K = W.shape[0]
+    logits = empty(N, K, like=pooled)
+    _lib.check(_lib_().tamgcn_head_fc_fwd(_ptr(pooled), _ptr(W), _ptr(b), N, C_, K, _ptr(logits), _stream()), 'tamgcn_head_fc_fwd')
+    return logits
+
+
+def head_fc_bwd(dlogits, pooled, W):
+    N, C_ = pooled.shape
+    K = W.shape[0]
+    dW, db, dpooled = torch.empty_like(W), empty(K, like=W), torch.empty_like(pooled)
+    _lib.check(_lib_().tamgcn_head_fc_bwd(_ptr(dlogits), _ptr(pooled), _ptr(W), N, C_, K, _ptr(dW), _ptr(db), _ptr(dpooled), _stream()),
+               'tamgcn_head_fc_bwd')
+    return dW, db, dpooled

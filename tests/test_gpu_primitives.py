@@ -319,3 +319,45 @@ def test_split_fp32_modes_against_fp64(mode, bar):
         assert max(errs[k]) <= bar, (k, errs[k])
     if mode == '1':                                              # and the split really is in use where it should be
         assert max(errs['wgrad']) > 1e-6
+
+
+@pytest.mark.parametrize('shape,training', [((3, 3, 7, 25, 2), True), ((4, 3, 13, 20, 1), True), ((3, 3, 7, 25, 2), False)])
+def test_stem_and_head_against_torch(shape, training):
+    """data_bn + permutes (reference models/ctrgcn.py:328-332) and mean-pool + fc (:343-348) against the
+    stock ops they replace, forward, backward, running statistics."""
+    import copy
+    from tam_gcn_amd import functional as Fn
+    N, C_, T, V, M = shape
+    d = dev()
+    torch.manual_seed(0)
+    bn = torch.nn.BatchNorm1d(M * V * C_)
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.1 * torch.randn(M * V * C_)); bn.bias.copy_(0.1 * torch.randn(M * V * C_))
+        bn.running_mean.copy_(0.1 * torch.randn(M * V * C_)); bn.running_var.copy_(0.5 + torch.rand(M * V * C_))
+    bn.train(training)
+    bng = copy.deepcopy(bn).to(d)
+    x = rnd(shape, 1).requires_grad_(True)
+    y = bn(x.permute(0, 4, 3, 1, 2).contiguous().view(N, M * V * C_, T))
+    y = y.view(N, M, V, C_, T).permute(0, 1, 3, 4, 2).contiguous().view(N * M, C_, T, V)
+    cot = rnd(tuple(y.shape), 2)
+    (y * cot).sum().backward()
+    xg = x.detach().to(d).requires_grad_(True)
+    yg = Fn.StemFn.apply(bng, xg, bng.weight, bng.bias)
+    (yg * cot.to(d)).sum().backward()
+    close(yg, y, 1e-4, 1e-5, 'stem forward')
+    close(xg.grad, x.grad, 1e-3, 2e-5, 'stem dx')
+    close(bng.weight.grad, bn.weight.grad, 1e-3, 1e-4, 'data_bn dgamma'); close(bng.bias.grad, bn.bias.grad, 1e-3, 1e-4, 'data_bn dbeta')
+    close(bng.running_mean, bn.running_mean, 1e-5, 1e-6); close(bng.running_var, bn.running_var, 1e-5, 1e-6)
+    assert int(bng.num_batches_tracked) == int(bn.num_batches_tracked)
+    # head
+    Cf, K = 32, 10
+    h = rnd((N * M, Cf, T, V), 3).requires_grad_(True)
+    W, b = (rnd((K, Cf), 4) * 0.2).requires_grad_(True), rnd((K,), 5).requires_grad_(True)
+    lo = F.linear(h.view(N, M, Cf, -1).mean(3).mean(1), W, b)
+    cl = rnd((N, K), 6)
+    (lo * cl).sum().backward()
+    hg, Wg, bg = (t.detach().to(d).requires_grad_(True) for t in (h, W, b))
+    lg = Fn.HeadFn.apply(hg, Wg, bg, M)
+    (lg * cl.to(d)).sum().backward()
+    close(lg, lo, 1e-4, 1e-5, 'logits')
+    close(hg.grad, h.grad, 1e-4, 1e-7, 'head dx'); close(Wg.grad, W.grad, 1e-4, 1e-6, 'dW'); close(bg.grad, b.grad, 1e-4, 1e-6, 'db')
