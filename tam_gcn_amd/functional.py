@@ -209,17 +209,17 @@ def _gcn_backward(P, sv, dg, need_dx=True, extra_dx=None):
     cargs = (xs, pq, P.W3, P.B3, P.W4, P.B4, P.PA, P.alpha, Cin, Cout, S_, R, dy)
     fk.refork()                                        # dyb / coefb_y are ready on main
     with fk.on(1):                                     # the dE chain runs beside the dx3 -> dx chain
-        G['PA'], G['W4'], G['B4'], G['alpha'], dpq = ops.ctrgc_bwd_de(*cargs, x3=sv['x3'])
+        G['PA'], G['W4'], G['B4'], G['alpha'], dpq = ops.ctrgc_bwd_de(*cargs, x3=sv['x3'], per_subset=True)
         dpq4 = S(dpq.view(1, S_ * 2 * R, N, V))
-        G['W12'] = ops.wgrad(dpq4, S(xbar.view(1, Cin, N, V)), M=S_ * 2 * R, K=Cin)
+        G['W12'] = ops.wgrad(dpq4, S(xbar.view(1, Cin, N, V)), M=S_ * 2 * R, K=Cin, rows=[R] * (2 * S_))   # one tensor per parameter
         G['B12'] = dpq.sum((1, 2))
         dxbar = None
         if need_dx:
             dxbar, _ = ops.conv(dpq4, K=S_ * 2 * R, w=P.W12, bias=None, M=Cin, wmode=1)    # (1, Cin, N, V)
-    dx3, G['B3'] = ops.ctrgc_bwd_dx3(*cargs, E=sv['E'])
+    dx3, G['B3'] = ops.ctrgc_bwd_dx3(*cargs, E=sv['E'], per_subset=True)
     fk.refork()
     with fk.on(0):
-        G['W3'] = ops.wgrad(S(dx3), xs, M=S_ * Cout, K=Cin)
+        G['W3'] = ops.wgrad(S(dx3), xs, M=S_ * Cout, K=Cin, rows=[Cout] * S_)
     fk.join(1)                                         # dxbar feeds the dx conv
     dx = None
     if need_dx:
@@ -380,12 +380,12 @@ def _tcn_backward(P, sv, dout, need_dg=True, need_dxres=True):
     dbin.append(dbias)
     for ev in marks:
         fk.wait(ev)                                    # the other branches' slices of dh / coefb_h
-    G['bin'] = torch.cat(dbin)
+    G['bin'] = dbin                                    # per branch (separate tensors: autograd adopts them without a copy)
     gs = S(g)
     gyh = S(dh, h_pre, coefb_h)
     fk.refork()                                        # dh and its BN-backward coefficients are ready
     with fk.on(0):
-        G['Win'] = ops.wgrad(gyh, gs, M=Ch, K=Cin)
+        G['Win'] = ops.wgrad(gyh, gs, M=Ch, K=Cin, rows=[Cb] * (nb + 1))
     with fk.on(1):
         G['Wl'] = ops.wgrad(gcat((nb + 1) * Cb), gs, M=Cb, K=Cin, stride=s)
     dg = None

@@ -240,12 +240,10 @@ class MultiScale_TemporalConv(nn.Module):
         nb = len(self._dils)
         Cb, Cin = self._bc, self.in_channels
         out = []
-        dWin = G['Win']
+        dWin, dbin = G['Win'], G['bin']                # lists: one tensor per branch
         for b in range(nb):
-            out += [dWin[b * Cb:(b + 1) * Cb].reshape(Cb, Cin, 1, 1), G['bin'][b * Cb:(b + 1) * Cb],
-                    G['bn_in'][b][0], G['bn_in'][b][1], G['Wt'][b], G['bt'][b], G['bn_t'][b][0], G['bn_t'][b][1]]
-        out += [dWin[nb * Cb:(nb + 1) * Cb].reshape(Cb, Cin, 1, 1), G['bin'][nb * Cb:(nb + 1) * Cb],
-                G['bn_in'][nb][0], G['bn_in'][nb][1], G['bn_pool'][0], G['bn_pool'][1]]
+            out += [dWin[b], dbin[b], G['bn_in'][b][0], G['bn_in'][b][1], G['Wt'][b], G['bt'][b], G['bn_t'][b][0], G['bn_t'][b][1]]
+        out += [dWin[nb], dbin[nb], G['bn_in'][nb][0], G['bn_in'][nb][1], G['bn_pool'][0], G['bn_pool'][1]]
         out += [G['Wl'], G['bl'], G['bn_l'][0], G['bn_l'][1]]
         if self._rmode == 'conv' or ext_conv:
             out += [G['Wr'], G['br'], G['bnr'][0], G['bnr'][1]]
@@ -385,14 +383,10 @@ class unit_gcn(nn.Module):
         S_, Cin, Cout = self.num_subset, self.in_c, self.out_c
         R = self.convs[0].rel_channels
         out = [G['PA'], G['alpha']]
-        W12, B12, W3, B3, W4, B4 = G['W12'], G['B12'], G['W3'], G['B3'], G['W4'], G['B4']
-        W12 = W12.reshape(S_, 2, R, Cin)
-        B12 = B12.reshape(S_, 2, R)
-        W3 = W3.reshape(S_, Cout, Cin)
-        B3 = B3.reshape(S_, Cout)
+        W12, W3, B3, W4, B4 = G['W12'], G['W3'], G['B3'], G['W4'], G['B4']     # lists: one tensor per parameter
+        B12 = G['B12'].reshape(S_, 2, R)
         for i in range(S_):
-            out += [W12[i, 0].reshape(R, Cin, 1, 1), B12[i, 0], W12[i, 1].reshape(R, Cin, 1, 1), B12[i, 1],
-                    W3[i].reshape(Cout, Cin, 1, 1), B3[i], W4[i].reshape(Cout, R, 1, 1), B4[i]]
+            out += [W12[2 * i], B12[i, 0], W12[2 * i + 1], B12[i, 1], W3[i], B3[i], W4[i], B4[i]]
         out += [G['bn.w'], G['bn.b']]
         if self._mode == 'conv':
             out += [G['Wd'].reshape(Cout, Cin, 1, 1), G['bd'], G['bnd.w'], G['bnd.b']]

@@ -95,8 +95,8 @@ def conv(src, K, w, bias, M, KT=1, dil=1, stride=1, pad=0, wmode=0, up=1,
 WGRAD_BLOCKS = int(os.environ.get('TAMGCN_WGRAD_BLOCKS', '512'))    # workgroups a weight gradient aims at (tiles x splits)
 
 
-def wgrad(gy, src, M, K, KT=1, dil=1, stride=1, pad=0):
-    """Returns dW (M, K, KT, 1)."""
+def wgrad(gy, src, M, K, KT=1, dil=1, stride=1, pad=0, rows=None):
+    """Returns dW (M, K, KT, 1); with rows = [m0, m1, ...] (summing to M) a list of separate (m_i, K, KT, 1) tensors."""
     N, _, T_out, V = gy.x1.shape
     T_in = src.x1.shape[2]
     # same tile rule as wgrad_tile() in csrc/conv.hip: aim at ~4 resident workgroups per CU
@@ -116,6 +116,8 @@ def wgrad(gy, src, M, K, KT=1, dil=1, stride=1, pad=0):
     part = empty(nsplit, M, K, KT, like=gy.x1)
     d.part, d.nsplit = _ptr(part), nsplit
     _lib.check(lib.tamgcn_wgrad(C.byref(d), _stream()), 'tamgcn_wgrad')
+    if rows is not None:
+        return reduce_sum(part, nsplit, chunks=[(m, K, KT, 1) for m in rows])
     if nsplit == 1:
         return part.view(M, K, KT, 1)
     return reduce_sum(part, nsplit).view(M, K, KT, 1)
@@ -136,25 +138,51 @@ class ReduceBatch:
         ReduceBatch._active = self.prev
         if self.items and exc[0] is None:
             arr = (ReduceDesc * len(self.items))()
-            for i, (part, nsplit, count, scale, acc, out) in enumerate(self.items):
-                arr[i] = ReduceDesc(_ptr(part), _ptr(out), nsplit, int(acc), count, count, scale)
+            for i, (part, nsplit, stride, off, count, scale, acc, out) in enumerate(self.items):
+                arr[i] = ReduceDesc(part.data_ptr() + 4 * off, _ptr(out), nsplit, int(acc), stride, count, scale)
             _lib.check(_lib_().tamgcn_reduce_multi(arr, len(self.items), _stream()), 'tamgcn_reduce_multi')
         self.items = []
         return False
 
 
-def reduce_sum(part, nsplit, scale=1.0, out=None, accumulate=False):
-    """part [nsplit][...] -> sum over the leading dim (deferred to the enclosing ReduceBatch, if any)."""
+def reduce_sum(part, nsplit, scale=1.0, out=None, accumulate=False, chunks=None):
+    """part [nsplit][...] -> sum over the leading dim (deferred to the enclosing ReduceBatch, if any).
+
+    chunks = list of shapes: the reduced vector is delivered as that many SEPARATE tensors (consecutive pieces), so that
+    gradients of parameters a kernel treats as one packed operand leave as tensors autograd can adopt without a copy."""
     count = part.numel() // nsplit
+    if chunks is not None:
+        outs, off = [], 0
+        flat = part.view(nsplit, count)
+        for shp in chunks:
+            n = 1
+            for d_ in shp:
+                n *= d_
+            o = torch.empty(shp, device=part.device, dtype=torch.float32)
+            _reduce_piece(flat, nsplit, count, off, n, scale, o)
+            outs.append(o)
+            off += n
+        assert off == count, 'reduce_sum: chunk shapes do not cover the slab'
+        return outs
     if out is None:
         out = torch.empty(part.shape[1:], device=part.device, dtype=torch.float32)
+    _reduce_piece(part, nsplit, count, 0, count, scale, out, accumulate)
+    return out
+
+
+def _reduce_piece(part, nsplit, stride, off, count, scale, out, accumulate=False):
     rb = ReduceBatch._active
     if rb is not None:
-        rb.items.append((part, nsplit, count, scale, accumulate, out))     # keeps `part` alive until the launch
-        return out
-    _lib.check(_lib_().tamgcn_reduce_sum(_ptr(part), nsplit, count, count, scale, int(accumulate), _ptr(out), _stream()),
+        rb.items.append((part, nsplit, stride, off, count, scale, accumulate, out))   # keeps `part` alive until the launch
+        return
+    src = C.c_void_p(part.data_ptr() + 4 * off)
+    if nsplit > 128:                                       # the two-stage kernel reduces in place: on a private copy of the piece
+        tmp = part.view(nsplit, stride)[:, off:off + count].contiguous()
+        _lib.check(_lib_().tamgcn_reduce_sum(_ptr(tmp), nsplit, count, count, scale, int(accumulate), _ptr(out), _stream()),
+                   'tamgcn_reduce_sum')
+        return
+    _lib.check(_lib_().tamgcn_reduce_sum(src, nsplit, stride, count, scale, int(accumulate), _ptr(out), _stream()),
                'tamgcn_reduce_sum')
-    return out
 
 
 # ---------------------------------------------------------------------------
@@ -218,7 +246,7 @@ def ctrgc_fwd(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, stats, keep_x3=F
     return y, part, x3
 
 
-def ctrgc_bwd_dx3(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy, E=None):
+def ctrgc_bwd_dx3(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy, E=None, per_subset=False):
     """dx3 (N,S*Cout,T,V) = E^T . dy, and db3 [S*Cout]."""
     N, _, T, V = x.x1.shape
     d = _ctrgc_desc(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, E)
@@ -227,10 +255,10 @@ def ctrgc_bwd_dx3(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy, E=None):
     db3_part = empty(N, S * Cout, like=x.x1)
     _lib.check(_lib_().tamgcn_ctrgc_bwd_dx3(C.byref(d), C.byref(dyc), _ptr(dx3), _ptr(db3_part), _stream()),
                'tamgcn_ctrgc_bwd_dx3')
-    return dx3, reduce_sum(db3_part, N)
+    return dx3, (reduce_sum(db3_part, N, chunks=[(Cout,)] * S) if per_subset else reduce_sum(db3_part, N))
 
 
-def ctrgc_bwd_de(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy, x3=None):
+def ctrgc_bwd_de(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy, x3=None, per_subset=False):
     """The dE chain: dA [S,V,V], dw4 [S,Cout,R], db4 [S,Cout], dalpha [1], dpq [S*2*R,N,V].
 
     With x3 (kept by ctrgc_fwd) and R <= 32: a streaming accumulation of dE plus one per-(n, s)
@@ -255,8 +283,9 @@ def ctrgc_bwd_de(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy, x3=None):
         _lib.check(_lib_().tamgcn_ctrgc_bwd_de_tail(C.byref(d), _ptr(dE), _ptr(dA_part), _ptr(dw4_part), _ptr(db4_part),
                                                     _ptr(dal_part), _ptr(dpq), G, _stream()), 'tamgcn_ctrgc_bwd_de_tail')
         dpq = dpq[0] if G == 1 else reduce_sum(dpq, G)
-        return (reduce_sum(dA_part, N * G), reduce_sum(dw4_part, N), reduce_sum(db4_part, N),
-                reduce_sum(dal_part, N * S * G), dpq)
+        ps = per_subset
+        return (reduce_sum(dA_part, N * G), reduce_sum(dw4_part, N, chunks=[(Cout, R, 1, 1)] * S if ps else None),
+                reduce_sum(db4_part, N, chunks=[(Cout,)] * S if ps else None), reduce_sum(dal_part, N * S * G), dpq)
     nct = Cout // 16
     dA_part = empty(N * nct, S, V, V, like=like)
     dw4_part = empty(N, S, Cout, R, like=like)
@@ -265,8 +294,9 @@ def ctrgc_bwd_de(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy, x3=None):
     dpq = torch.zeros(S * 2 * R, N, V, device=like.device, dtype=torch.float32)
     _lib.check(_lib_().tamgcn_ctrgc_bwd_de(C.byref(d), C.byref(dyc), _ptr(dA_part), _ptr(dw4_part), _ptr(db4_part),
                                            _ptr(dal_part), _ptr(dpq), _stream()), 'tamgcn_ctrgc_bwd_de')
-    return (reduce_sum(dA_part, N * nct), reduce_sum(dw4_part, N), reduce_sum(db4_part, N),
-            reduce_sum(dal_part, N * nct), dpq)
+    ps = per_subset
+    return (reduce_sum(dA_part, N * nct), reduce_sum(dw4_part, N, chunks=[(Cout, R, 1, 1)] * S if ps else None),
+            reduce_sum(db4_part, N, chunks=[(Cout,)] * S if ps else None), reduce_sum(dal_part, N * nct), dpq)
 
 
 def ctrgc_bwd(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy, x3=None):
