@@ -240,11 +240,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
+    # Rehearsal hooks (a one-GPU box cannot run RCCL between two ranks): TAMGCN_BENCH_ONE_DEVICE=1 puts every rank on
+    # cuda:0 and TAMGCN_DIST_BACKEND=gloo moves the collectives to gloo -- same control flow, not a measurement.
+    if os.environ.get('TAMGCN_BENCH_ONE_DEVICE') == '1':
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
+        backend = os.environ.get('TAMGCN_DIST_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from tam_gcn_amd import _lib
     from tam_gcn_amd.distributed import FlatGradBucket, ParamArena, SGDNesterov, broadcast_state
