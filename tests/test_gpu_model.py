@@ -194,3 +194,33 @@ def test_harness_sgd_steps(flat, golden_models):
     # several per cent of the state (the oracle, bit-compatible arithmetic, holds 2e-4: tests/test_model_cpu.py): sanity bar
     bad = np.abs(got[:, 1] - refd[:, 1]) > 0.1 * np.abs(refd[:, 1]) + 1e-2
     assert not bad.any(), [(k, got[i, 1], refd[i, 1]) for i, k in enumerate(sd.keys()) if bad[i]][:5]
+
+
+def test_frozen_backbone_usage():
+    """The cross-modal caller freezes the CTR-GCN and reads extract_feature (reference models/resnet_gcn_attention.py:24-26,
+    82-85): frozen parameters get no gradients, a downstream head still trains, and a gradient w.r.t. the input equals the
+    one of the unfrozen model."""
+    dev = torch.device('cuda:0')
+    m = M.Model(**MODEL_CASES[0][1])
+    fill_state_(m.state_dict(), seed=MODEL_PARAM_SEED)
+    m = m.to(dev).eval()
+    x = make_input((2, 3, 52, 20, 1), seed=MODEL_X_SEED).to(dev)
+    xr = x.clone().requires_grad_(True)
+    f_ref, _ = m.extract_feature(xr)
+    assert tuple(f_ref.shape) == (2, 256, 13, 20, 1)                      # the shape comment at resnet_gcn_attention.py:81
+    f_ref.square().mean().backward()
+    g_unfrozen = xr.grad.clone()
+    for p in m.parameters():
+        p.requires_grad = False
+        p.grad = None
+    head = torch.nn.Linear(256, 4).to(dev)
+    f, f2 = m.extract_feature(x)                                           # input without grad: nothing to differentiate upstream
+    assert f is f2 and not f.requires_grad
+    out = head(f.mean((2, 3, 4)))
+    out.sum().backward()
+    assert head.weight.grad is not None and all(p.grad is None for p in m.parameters())
+    xr2 = x.clone().requires_grad_(True)
+    f3, _ = m.extract_feature(xr2)
+    f3.square().mean().backward()
+    assert all(p.grad is None for p in m.parameters())
+    assert torch.allclose(xr2.grad, g_unfrozen, rtol=1e-4, atol=1e-7)
