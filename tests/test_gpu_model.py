@@ -224,3 +224,16 @@ def test_frozen_backbone_usage():
     f3.square().mean().backward()
     assert all(p.grad is None for p in m.parameters())
     assert torch.allclose(xr2.grad, g_unfrozen, rtol=1e-4, atol=1e-7)
+
+
+def test_dataparallel_wrapper_single_device():
+    """The harness wraps the model in nn.DataParallel (reference processor/io.py:86-87); on one device that is a plain call."""
+    dev = torch.device('cuda:0')
+    m = M.Model(**MODEL_CASES[0][1])
+    fill_state_(m.state_dict(), seed=MODEL_PARAM_SEED)
+    m = m.to(dev).eval()
+    x = make_input((2, 3, 13, 20, 1), seed=MODEL_X_SEED).to(dev)
+    dp = torch.nn.DataParallel(m, device_ids=[0])
+    with torch.no_grad():
+        assert torch.equal(dp(x), m(x))
+    assert [k for k in dp.state_dict()][0].startswith('module.')

@@ -1,0 +1,39 @@
+"""GPU-box tool: forward-only throughput (eval mode, no_grad) of the N-UCLA model at a few batch sizes -- what the
+inference-only callers (cross-modal attention, ensemble eval, visualisation) see.  Eager launches and HIP-graph replay."""
+import os, sys, time, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tam_gcn_amd.models.ctrgcn import Model
+dev = torch.device('cuda:0')
+torch.manual_seed(0)
+m = Model(num_class=10, num_point=20, num_person=1, graph='graph.ucla.Graph', graph_args=dict(labeling_mode='spatial')).to(dev).eval()
+with torch.no_grad():
+    for k, p in m.named_parameters():
+        if k.endswith('alpha'):
+            p.fill_(0.5)
+for B in (1, 16, 256):
+    x = torch.rand(B, 3, 64, 20, 1, device=dev) * 2 - 1
+    with torch.no_grad():
+        for _ in range(3):
+            y = m(x)
+        torch.cuda.synchronize()
+        n = 20
+        t0 = time.perf_counter()
+        for _ in range(n):
+            y = m(x)
+        torch.cuda.synchronize()
+        eager = (time.perf_counter() - t0) / n
+        s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            y = m(x)
+        torch.cuda.current_stream().wait_stream(s); torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            y = m(x)
+        g.replay(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            g.replay()
+        torch.cuda.synchronize()
+        graph = (time.perf_counter() - t0) / n
+    print(f'batch {B:4d}: eager {eager * 1e3:7.2f} ms ({B / eager:9.0f} clips/s)   hip graph {graph * 1e3:7.2f} ms ({B / graph:9.0f} clips/s)', flush=True)
