@@ -237,3 +237,41 @@ def test_dataparallel_wrapper_single_device():
     with torch.no_grad():
         assert torch.equal(dp(x), m(x))
     assert [k for k in dp.state_dict()][0].startswith('module.')
+
+
+def test_full_size_properties():
+    """BASELINE configs[1] at its full size (256 clips x 3 x 64 x 20): no oracle run is affordable here, so the properties
+    the domain offers.  (1) eval mode: a clip's logits do not depend on its batch (full grids, XCD mapping, every tile path
+    vs a 4-clip launch); (2) train mode: permuting the batch permutes the logits (BatchNorm statistics are order-free up to
+    summation order) and leaves the summed loss gradient of a parameter unchanged."""
+    dev = torch.device('cuda:0')
+    m = M.Model(**MODEL_CASES[0][1])
+    fill_state_(m.state_dict(), seed=MODEL_PARAM_SEED)
+    m = m.to(dev)
+    g = torch.Generator().manual_seed(11)
+    x = (torch.rand(256, 3, 64, 20, 1, generator=g) * 2 - 1).to(dev)
+    lab = torch.randint(0, 10, (256,), generator=g).to(dev)
+    m.train()                                            # one step with momentum 1: running statistics := batch statistics
+    for mod in m.modules():
+        if isinstance(mod, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            mod.momentum = 1.0
+    with torch.no_grad():
+        m(x)
+    m.eval()
+    with torch.no_grad():
+        full = m(x)
+        sub = m(x[100:104].contiguous())
+    assert torch.isfinite(full).all()
+    assert (full[100:104] - sub).abs().max() <= 1e-4 * full.abs().max()
+    m.train()
+    perm = torch.randperm(256, generator=g).to(dev)
+    out = m(x)
+    torch.nn.functional.cross_entropy(out, lab, reduction='sum').backward()
+    g1 = m.l10.tcn1.branches[0][3].conv.weight.grad.clone()
+    for p in m.parameters():
+        p.grad = None
+    outp = m(x[perm].contiguous())
+    torch.nn.functional.cross_entropy(outp, lab[perm], reduction='sum').backward()
+    g2 = m.l10.tcn1.branches[0][3].conv.weight.grad
+    assert (outp - out[perm]).abs().max() <= 2e-4 * out.abs().max()
+    assert (g1 - g2).norm() <= 2e-3 * g1.norm()
