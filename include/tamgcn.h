@@ -121,7 +121,8 @@ typedef struct tamgcn_wgrad_desc {
 int tamgcn_wgrad_max_split(const tamgcn_wgrad_desc* d);
 int tamgcn_wgrad(const tamgcn_wgrad_desc* d, void* stream);
 
-/* Several slab reductions in ONE launch (a layer's backward produces ~25 of them): for each descriptor
+/* Several slab reductions in ONE launch (a layer's backward produces ~25 of them; the sums over (n, t, v) of aten's
+ * convolution_backward / native_batch_norm_backward for the modules of reference models/ctrgcn.py:53-284): for each descriptor
  * out[e] (+)= scale * sum_s part[s*stride_s + e], fp64 accumulation in a fixed order. */
 typedef struct tamgcn_reduce_desc {
     const float* part; float* out;
@@ -184,7 +185,7 @@ typedef struct tamgcn_ctrgc_desc {
 } tamgcn_ctrgc_desc;
 
 /* E[n,s,c,u,v] = alpha*(W4_s tanh(p_s[n,:,u] - q_s[n,:,v]) + b4_s)[c] + A_s[u,v] for every channel, once per
- * layer and sample (R <= 32); pass it as d->E to tamgcn_ctrgc_fwd and tamgcn_ctrgc_bwd_dx3. */
+ * layer and sample (R <= 32): reference models/ctrgcn.py:174-176 (tanh of the pairwise difference, conv4, * alpha + A); pass it as d->E to tamgcn_ctrgc_fwd and tamgcn_ctrgc_bwd_dx3. */
 int tamgcn_ctrgc_build_e(const tamgcn_ctrgc_desc* d, float* E, void* stream);
 
 /* y[n,c,t,u] = sum_s sum_v E_s[n,c,u,v] * (W3_s x + b3_s)[n,c,t,v],
@@ -208,7 +209,8 @@ int tamgcn_ctrgc_bwd_de(const tamgcn_ctrgc_desc* d, const tamgcn_src* dy,
                         float* dA_part, float* dw4_part, float* db4_part, float* dalpha_part,
                         float* dpq, void* stream);
 
-/* The same chain when tamgcn_ctrgc_fwd kept x3 (x3_out), as two launches:
+/* The same chain (autograd of reference models/ctrgcn.py:172-177 w.r.t. PA, alpha, conv4, conv1/conv2 outputs) when
+ * tamgcn_ctrgc_fwd kept x3 (x3_out), as two launches:
  *   _de_acc   dE (N, S, Cout, V, V) = sum_t dy(n,c,t,u) * x3[n, s*Cout+c, t, v]     (streaming, HBM-bound)
  *   _de_tail  one workgroup per (n, s, channel group g of `groups`): dA_part [N*groups][S][V][V],
  *             dw4_part [N][S][Cout][R], db4_part [N][S][Cout], dalpha_part [N*S*groups],
