@@ -4,8 +4,14 @@ of models.ctrgcn.Model on the N-UCLA joint stream (20 joints x 64 frames), BASEL
 configs[1]: batch 256 per GPU, synthetic U(-1,1) clips, seeded init (de-degenerated so
 every branch of the block does real work).
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W] [--config ucla|4stream]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+`python bench.py --gpus N` with N > 1 and no launcher environment starts N fresh rank processes itself
+(torch.distributed.run, rendezvous on 127.0.0.1) BEFORE anything touches the GPU, forwards rank 0's JSON
+line and exits with the children's code.  --config 4stream is BASELINE.json configs[2]: four Models
+(joint / bone / joint-motion / bone-motion, derived on the GPU from the joint clips), 128 clips per GPU
+and stream, ONE concatenated gradient bucket (4 x 6.77 MB) and one all-reduce per step.
 
 One rank per GPU; the clip batch is sharded (weak scaling: 256 clips per GPU), gradients
 are averaged with ONE flat-bucket RCCL all-reduce (6.77 MB) per step.  The step is
@@ -65,7 +71,8 @@ class _Probe:
     def __getattr__(self, name):
         fn = getattr(self._lib, name)
         if not name.startswith('tamgcn_') or name in ('tamgcn_last_error', 'tamgcn_last_kernel', 'tamgcn_version', 'tamgcn_conv_nparts',
-                                                     'tamgcn_ew_nparts', 'tamgcn_ctrgc_lds_bytes'):
+                                                     'tamgcn_ew_nparts', 'tamgcn_ctrgc_lds_bytes', 'tamgcn_get_split_mode',
+                                                     'tamgcn_set_split_mode', 'tamgcn_wgrad_max_split'):
             return fn
 
         def wrapped(*args):
@@ -77,13 +84,21 @@ class _Probe:
             rc = fn(*args)
             e1.record()
             sym = self._lib.tamgcn_last_kernel().decode()
-            self.records.append((sym or name, e0, e1, _algorithmic(name, args)))
+            self.records.append((sym or name, e0, e1, _algorithmic(name, args), _layer_tag(name, args)))
             return rc
         return wrapped
 
 
 def _src_reads(s):
     return 1 + (1 if s.x2 else 0)
+
+
+def _layer_tag(name, args):
+    """'Cin->Cout,T' of a fused-CTRGC forward launch (the per-layer roofline table), else None."""
+    if name != 'tamgcn_ctrgc_fwd':
+        return None
+    d = args[0]._obj
+    return f'{d.Cin}->{d.Cout},T{d.T},V{d.V}'
 
 
 def _algorithmic(name, args):
@@ -122,14 +137,29 @@ def instrumented_pass(step_fn, probe, steps):
         step_fn()
     torch.cuda.synchronize()
     probe.on = False
-    agg = {}
-    for name, e0, e1, (b, f) in probe.records:
-        a = agg.setdefault(name, dict(calls=0, ms=0.0, bytes=0.0, flops=0.0))
-        a['calls'] += 1
-        a['ms'] += e0.elapsed_time(e1)
-        a['bytes'] += b
-        a['flops'] += f
-    return agg
+    agg, layers = {}, {}
+    for name, e0, e1, (b, f), tag in probe.records:
+        ms = e0.elapsed_time(e1)
+        for table, key in ((agg, name),) + (((layers, tag),) if tag else ()):
+            a = table.setdefault(key, dict(calls=0, ms=0.0, bytes=0.0, flops=0.0))
+            a['calls'] += 1
+            a['ms'] += ms
+            a['bytes'] += b
+            a['flops'] += f
+    return agg, layers
+
+
+def ctrgc_layer_table(layers):
+    """Per-layer roofline of the fused CTRGC forward (both fractions, binding roof named)."""
+    rows = []
+    for tag, a in layers.items():
+        sec = a['ms'] * 1e-3 / a['calls']
+        b, f = a['bytes'] / a['calls'], a['flops'] / a['calls']
+        t_h, t_m = b / HBM_PEAK, f / F32_MFMA_PEAK
+        rows.append(dict(layer=tag, launches=a['calls'], avg_us=round(sec * 1e6, 1), hbm_frac=round(b / sec / HBM_PEAK, 4),
+                         mfma_f32_frac=round(f / sec / F32_MFMA_PEAK, 4), binding='mfma' if t_m > t_h else 'hbm',
+                         frac_of_binding=round(max(t_h, t_m) / sec, 4)))
+    return rows
 
 
 def roofline_of(agg):
@@ -143,12 +173,18 @@ def roofline_of(agg):
     sec = a['ms'] * 1e-3
     bw, fl = a['bytes'] / sec, a['flops'] / sec
     t_hbm, t_mfma = a['bytes'] / HBM_PEAK, a['flops'] / F32_MFMA_PEAK
-    traffic = None
-    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')        # filled from rocprofv3 --pmc passes
+    # HBM bytes per launch come from rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950 note, WRITE_SIZE), which
+    # cannot run inside this process: the figure is the committed one of the named profile, labelled with its source,
+    # and null when that profile has no row for this kernel symbol.
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
     if os.path.exists(tpath):
-        t = json.load(open(tpath)).get(name)
+        tj = json.load(open(tpath))
+        t = tj.get(name)
         traffic = t.get('hbm_bytes_per_launch') if isinstance(t, dict) else t
-    common = dict(kernel=name, launches=a['calls'], avg_launch_us=1e3 * a['ms'] / a['calls'],
+        if traffic is not None:
+            traffic_src = 'profiles/traffic.json (' + str(tj.get('_source', 'rocprofv3 --pmc, earlier run of this command')) + ')'
+    common = dict(kernel=name, launches=a['calls'], avg_launch_us=1e3 * a['ms'] / a['calls'], traffic_source=traffic_src,
                   algorithmic_bytes_per_launch=a['bytes'] / a['calls'], algorithmic_flops_per_launch=a['flops'] / a['calls'],
                   hbm_frac=bw / HBM_PEAK, mfma_f32_frac=fl / F32_MFMA_PEAK, traffic=traffic)
     if t_mfma > t_hbm:
@@ -185,10 +221,11 @@ def _log(msg):
 _T0 = time.perf_counter()
 
 
-def cpu_baseline(budget_s=15.0):
-    """The oracle (kind 'port': our stock-PyTorch restatement, pinned to the reference by
-    tests/golden) on the host cores: fwd + CE + bwd + SGD step, B=16 (the reference's batch
-    size, config/nucla/gcn.yaml:37), T=64, V=20."""
+def cpu_baseline(budget_s=24.0):
+    """The oracle (kind 'port': our stock-PyTorch restatement, pinned to the reference by tests/golden) on the host
+    cores, forward + CE + backward (optimizer step excluded).  `value` is the leg with the GPU line's
+    own workload (batch 256, T = 64); the reference's batch size (16, config/nucla/gcn.yaml:37) and real clip length
+    (T = 52, feeder/feeder_nucla_gcn.py:26) are reported beside it.  Bounded: about `budget_s` seconds in all."""
     from oracle import ctrgcn_oracle as O
     from tam_gcn_amd.models.ctrgcn import Model
     cores = host_cores()
@@ -198,139 +235,207 @@ def cpu_baseline(budget_s=15.0):
     dedegenerate_(m)
     sd = O.clone_state(m.state_dict(), requires_grad=True)
     params = [v for v in sd.values() if v.requires_grad]
-    B = 16
-    g = torch.Generator().manual_seed(1234)
-    x = torch.rand(B, 3, T_FRAMES, V_JOINTS, 1, generator=g) * 2 - 1
-    lab = torch.randint(0, 10, (B,), generator=g)
 
-    def step():
-        for p in params:
-            p.grad = None
-        loss = torch.nn.functional.cross_entropy(O.model_forward(x, sd, 20, training=True), lab)
-        loss.backward()
-        with torch.no_grad():
+    def leg(B, T, budget, max_steps):
+        g = torch.Generator().manual_seed(1234)
+        x = torch.rand(B, 3, T, V_JOINTS, 1, generator=g) * 2 - 1
+        lab = torch.randint(0, 10, (B,), generator=g)
+
+        def step():
             for p in params:
-                p.add_(p.grad, alpha=-1e-3)
+                p.grad = None
+            torch.nn.functional.cross_entropy(O.model_forward(x, sd, 20, training=True), lab).backward()
 
-    t0 = time.perf_counter(); step(); t1 = time.perf_counter() - t0
-    _log(f'cpu baseline: {cores} threads, first step {t1:.2f}s')
-    n = max(1, min(48, int(budget_s / max(t1, 1e-3)) - 1))      # about 10-15 s of CPU work
-    t0 = time.perf_counter()
-    for _ in range(n):
-        step()
-    dt = time.perf_counter() - t0
-    return dict(value=B * n / dt, unit='clips/s', cores=torch.get_num_threads(), kind='port',
-                sample=f'{n} steps of batch {B} (T=64,V=20) fwd+CE+bwd+SGD after 1 warm-up, {dt:.1f}s')
+        t0 = time.perf_counter(); step(); t1 = time.perf_counter() - t0
+        n = max(1, min(max_steps, int(budget / max(t1, 1e-3))))
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        dt = time.perf_counter() - t0
+        _log(f'cpu baseline: B={B} T={T}: {n} steps in {dt:.1f}s on {cores} threads')
+        return dict(batch=B, T=T, clips_per_s=B * n / dt, steps=n, seconds=round(dt, 2))
+
+    legs = [leg(16, T_FRAMES, budget_s * 0.2, 24), leg(16, 52, budget_s * 0.15, 24), leg(PER_GPU_BATCH, T_FRAMES, budget_s * 0.45, 3)]
+    main_leg = legs[2]
+    return dict(value=main_leg['clips_per_s'], unit='clips/s', cores=torch.get_num_threads(), kind='port',
+                sample=f"{main_leg['steps']} steps of batch {PER_GPU_BATCH} (T=64,V=20) fwd+CE+bwd after 1 warm-up, "
+                       f"{main_leg['seconds']}s; optimizer step excluded",
+                legs=legs)
 
 
 # ---------------------------------------------------------------------------
+# the N-UCLA bone table as a parent array (reference feeder/feeder_nucla_gcn.py:27-28: pair (v1, v2) at list
+# position v1 - 1; 0-based parent of joint v = v2 - 1)
+UCLA_BONE_PARENT = [1, 2, 2, 2, 2, 4, 5, 6, 2, 8, 9, 10, 0, 12, 13, 14, 0, 16, 17, 18]
+STREAMS = ('joint', 'bone', 'motion', 'bone_motion')
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _self_launch(n, argv):
+    """`python bench.py --gpus N` outside a launcher: start N fresh rank processes.  Runs before this process has made
+    any HIP / torch.cuda call (a process that has initialised the GPU must not be re-executed or forked from)."""
+    import subprocess
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    r = subprocess.run(cmd, env=env)                    # children inherit stdout: rank 0's JSON line is ours
+    raise SystemExit(r.returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=PER_GPU_BATCH, help='clips per GPU')
+    ap.add_argument('--batch', type=int, default=None, help='clips per GPU (per stream); default 256, 128 for --config 4stream')
+    ap.add_argument('--config', choices=('ucla', '4stream'), default='ucla')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
+    # TAMGCN_BENCH_REHEARSAL=1: the multi-rank CONTROL FLOW (spawn, rendezvous, broadcast, step, one flat all-reduce, flat SGD,
+    # barriers, max-over-ranks clock, rank 0's JSON line) on CPU tensors over gloo with a stand-in gradient fill instead
+    # of the HIP model: what tests/test_distributed_cpu.py drives with world size 2.  Never a measurement: `value` is null.
+    rehearsal = os.environ.get('TAMGCN_BENCH_REHEARSAL') == '1'
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        _self_launch(args.gpus, sys.argv[1:])
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
-    # Rehearsal hooks (a one-GPU box cannot run RCCL between two ranks): TAMGCN_BENCH_ONE_DEVICE=1 puts every rank on
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks')
+    # Rehearsal hooks for a one-GPU box (RCCL needs one device per rank): TAMGCN_BENCH_ONE_DEVICE=1 puts every rank on
     # cuda:0 and TAMGCN_DIST_BACKEND=gloo moves the collectives to gloo -- same control flow, not a measurement.
     if os.environ.get('TAMGCN_BENCH_ONE_DEVICE') == '1':
         local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
+    if rehearsal:
+        dev = torch.device('cpu')
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        backend = os.environ.get('TAMGCN_DIST_BACKEND', 'nccl')
+        backend = 'gloo' if rehearsal else os.environ.get('TAMGCN_DIST_BACKEND', 'nccl')
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)
         else:
             dist.init_process_group(backend)
 
-    from tam_gcn_amd import _lib
-    from tam_gcn_amd.distributed import FlatGradBucket, ParamArena, SGDNesterov, broadcast_state
+    from tam_gcn_amd.distributed import ParamArena, SGDNesterov, broadcast_state
     from tam_gcn_amd.models.ctrgcn import Model
-    probe = _Probe(_lib.load())
-    _lib._lib = probe                                     # every ABI launch goes through the probe
+    probe = None
+    if not rehearsal:
+        from tam_gcn_amd import _lib
+        probe = _Probe(_lib.load())
+        _lib._lib = probe                                 # every ABI launch goes through the probe
 
+    four = args.config == '4stream'
+    B = args.batch or (128 if four else PER_GPU_BATCH)
+    streams = STREAMS if four else ('joint',)
     torch.manual_seed(0)
-    model = Model(**MODEL_ARGS)
-    dedegenerate_(model)
-    model = model.to(dev).train()
-    arena = ParamArena(model)                             # parameters in one flat buffer: zero-copy operand packing, flat SGD
-    broadcast_state(model)
-    bucket = arena.grad_bucket()
+    models = torch.nn.ModuleList()
+    for i, _ in enumerate(streams):                       # independent models, as the 4-stream recipe trains them
+        m = Model(**MODEL_ARGS)
+        dedegenerate_(m, seed=i)
+        models.append(m)
+    models = models.to(dev).train()
+    arena = ParamArena(models)                            # every model's parameters in ONE flat buffer ...
+    broadcast_state(models)
+    bucket = arena.grad_bucket()                          # ... and ONE congruent gradient bucket: one all-reduce per step
     opt = SGDNesterov(arena.params, lr=0.01, momentum=0.9, weight_decay=1e-4, arena=arena, bucket=bucket)
     g = torch.Generator().manual_seed(1234 + rank)
-    B = args.batch
     x = (torch.rand(B, 3, T_FRAMES, V_JOINTS, 1, generator=g) * 2 - 1).to(dev)
     lab = torch.randint(0, 10, (B,), generator=g).to(dev)
     loss_buf = torch.zeros((), device=dev)
+    parent = torch.tensor(UCLA_BONE_PARENT, dtype=torch.int32, device=dev)
 
-    def fwd_bwd():
-        bucket.zero()
-        loss = torch.nn.functional.cross_entropy(model(x), lab)
-        loss.backward()
-        bucket.pack()
-        loss_buf.copy_(loss.detach())
+    if rehearsal:
+        def fwd_bwd():
+            bucket.zero()
+            for i, p in enumerate(arena.params):          # stand-in gradients: deterministic, rank-dependent
+                p.grad = torch.full_like(p, 1e-3 * (rank + 1) * ((i % 7) - 3))
+            bucket.pack()
+            loss_buf.fill_(float(rank))
+    else:
+        from tam_gcn_amd import ops as _ops
+
+        def fwd_bwd():
+            bucket.zero()
+            total = None
+            for name, m in zip(streams, models):          # the streams are derived on the GPU from the resident joint clips
+                xs = x if name == 'joint' else _ops.stream_derive(x, parent, name)
+                loss = torch.nn.functional.cross_entropy(m(xs), lab)
+                total = loss if total is None else total + loss
+            total.backward()
+            bucket.pack()
+            loss_buf.copy_(total.detach() / len(streams))
 
     def eager_step():
         fwd_bwd()
         bucket.all_reduce_mean()
         opt.step()
 
-    _log('model built; eager warm-up')
-    # warm-up (also the side-stream warm-up HIP graph capture needs)
-    s = torch.cuda.Stream()
-    s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
-        for _ in range(max(2, args.warmup)):
-            eager_step()
-    torch.cuda.current_stream().wait_stream(s)
-    torch.cuda.synchronize()
+    def sync():
+        if not rehearsal:
+            torch.cuda.synchronize()
 
-    _log('warm-up done')
+    _log('model built; eager warm-up')
     mode = 'eager'
     step = eager_step
-    if not args.no_graph:
-        try:
-            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
-                fwd_bwd()
-            with torch.cuda.graph(g2):
-                opt.step()
+    if rehearsal:
+        for _ in range(max(1, args.warmup)):
+            eager_step()
+    else:
+        # warm-up (also the side-stream warm-up HIP graph capture needs)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(max(2, args.warmup)):
+                eager_step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        _log('warm-up done')
+        if not args.no_graph:
+            try:
+                g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1):
+                    fwd_bwd()
+                with torch.cuda.graph(g2):
+                    opt.step()
 
-            def graph_step():
-                g1.replay()
-                bucket.all_reduce_mean()
-                g2.replay()
-            step, mode = graph_step, 'hipgraph'
-            _log('graphs captured')
-            for _ in range(2):
-                step()
-            torch.cuda.synchronize()
-        except Exception as e:                            # noqa: BLE001
-            if rank == 0:
-                print(f'[bench] graph capture failed ({type(e).__name__}: {e}); timing eager launches', file=sys.stderr)
-            step, mode = eager_step, 'eager'
-            torch.cuda.synchronize()
+                def graph_step():
+                    g1.replay()
+                    bucket.all_reduce_mean()
+                    g2.replay()
+                step, mode = graph_step, 'hipgraph'
+                _log('graphs captured')
+                for _ in range(2):
+                    step()
+                torch.cuda.synchronize()
+            except Exception as e:                            # noqa: BLE001
+                if rank == 0:
+                    print(f'[bench] graph capture failed ({type(e).__name__}: {e}); timing eager launches', file=sys.stderr)
+                step, mode = eager_step, 'eager'
+                torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -342,33 +447,77 @@ def main():
     _log(f'timed {args.steps} steps in {dt:.3f}s ({mode})')
 
     out = None
-    # Per-kernel durations for the roofline: the same step, launched eagerly on ONE stream, HIP events around every ABI
-    # launch.  (With the side streams on, kernels overlap and an event pair measures the overlap, not the kernel:
-    # rocprofv3 --kernel-trace of that mode reports the same inflated durations.)
-    from tam_gcn_amd import functional as _F
-    side, _F.USE_SIDE_STREAMS = _F.USE_SIDE_STREAMS, False
-    agg = instrumented_pass(eager_step, probe, 2)         # every rank: the step contains a collective
-    _F.USE_SIDE_STREAMS = side
-    _log('instrumented pass done')
+    roof, shares, layer_rows, ms_exact = None, {}, [], None
+    split = 1
+    if not rehearsal:
+        # the same step with EVERY GEMM on the exact fp32-input MFMA (mode 0), re-captured, a few replays: reported beside
+        # the headline number, whose backward GEMMs use the 2-term bf16 split by default
+        lib = probe._lib
+        split = lib.tamgcn_get_split_mode()
+        if split != 0 and world == 1:
+            lib.tamgcn_set_split_mode(0)
+            try:
+                step0 = eager_step
+                if mode == 'hipgraph':
+                    g1x = torch.cuda.CUDAGraph()
+                    eager_step(); torch.cuda.synchronize()
+                    with torch.cuda.graph(g1x):
+                        fwd_bwd()
+
+                    def step0():
+                        g1x.replay()
+                        g2.replay()
+                for _ in range(2):
+                    step0()
+                torch.cuda.synchronize()
+                k0 = max(3, min(10, args.steps))
+                t0 = time.perf_counter()
+                for _ in range(k0):
+                    step0()
+                torch.cuda.synchronize()
+                ms_exact = 1e3 * (time.perf_counter() - t0) / k0
+            finally:
+                lib.tamgcn_set_split_mode(split)
+            _log(f'exact-fp32 (mode 0) step: {ms_exact:.2f} ms')
+    if not rehearsal:
+        # Per-kernel durations for the roofline: the same step, launched eagerly on ONE stream, HIP events around every ABI
+        # launch.  (With the side streams on, kernels overlap and an event pair measures the overlap, not the kernel:
+        # rocprofv3 --kernel-trace of that mode reports the same inflated durations.)
+        from tam_gcn_amd import functional as _F
+        side, _F.USE_SIDE_STREAMS = _F.USE_SIDE_STREAMS, False
+        agg, layers = instrumented_pass(eager_step, probe, 2)     # every rank: the step contains a collective
+        _F.USE_SIDE_STREAMS = side
+        _log('instrumented pass done')
+        if rank == 0:
+            roof, shares = roofline_of(agg)
+            layer_rows = ctrgc_layer_table(layers)
     if rank == 0:
-        roof, shares = roofline_of(agg)
-        cpu = None if args.no_cpu_baseline or world > 1 else cpu_baseline()
+        cpu = None if (args.no_cpu_baseline or world > 1 or rehearsal) else cpu_baseline()
+        split = str(split)
+        clips = world * B * args.steps * len(streams)
         out = {
-            'metric': 'skeleton clips/sec (fwd+bwd), N-UCLA 20-joint x 64-frame',
-            'value': world * B * args.steps / dt, 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'N-UCLA joint stream, {B} clips/GPU x (3,64,20,1), models.ctrgcn.Model '
-                                   f'fwd+CE+bwd+grad-allreduce+SGD step, train-mode BN',
-                       'global_batch': world * B, 'parallelism': f'dp{world}', 'launch': mode,
-                       'final_loss': final_loss},
-            'roofline': roof, 'cpu_baseline': cpu, 'abi_ms_per_2_steps': shares,
+            'metric': 'skeleton clips/sec (fwd+CE+bwd+grad all-reduce+SGD step), N-UCLA 20-joint x 64-frame',
+            'value': None if rehearsal else clips / dt, 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'ms_per_step_exact_f32': ms_exact, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None,
+            'dtype': {'0': 'f32 (exact fp32-input MFMA in every GEMM, TAMGCN_SPLIT_BF16=0)',
+                      '1': 'f32 (fwd GEMMs exact fp32-input MFMA; bwd weight-gradient and C>=128 data-gradient GEMMs 2-term '
+                           'bf16 split = 3 bf16 MFMAs, ~4.5e-6 rel. error, TAMGCN_SPLIT_BF16=1)',
+                      '2': 'f32 (as mode 1, and the forward x3 GEMM also 2-term bf16 split, TAMGCN_SPLIT_BF16=2)'}.get(split, split),
+            'data': 'synthetic',
+            'config': {'workload': (f'N-UCLA 4-stream (joint/bone/motion/bone-motion derived on GPU), 4 x models.ctrgcn.Model, '
+                                    f'{B} clips/GPU/stream x (3,64,20,1), ONE {arena.total * 4 / 1e6:.1f} MB gradient bucket' if four else
+                                    f'N-UCLA joint stream, {B} clips/GPU x (3,64,20,1), models.ctrgcn.Model') +
+                                   ' fwd+CE+bwd+grad-allreduce+SGD step, train-mode BN',
+                       'global_batch': world * B, 'streams': len(streams), 'parallelism': f'dp{world}', 'launch': mode,
+                       'final_loss': final_loss, 'rehearsal': rehearsal},
+            'roofline': roof, 'cpu_baseline': cpu, 'ctrgc_fwd_layers': layer_rows, 'abi_ms_per_2_steps': shares,
         }
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':

@@ -54,6 +54,14 @@ const char* tamgcn_last_error(void);
 /* symbol (template arguments included) of the kernel the calling thread's last ABI call launched;
  * lets a profiler attribute HIP-event timings to the rows of a rocprofv3 kernel trace */
 const char* tamgcn_last_kernel(void);
+/* GEMM arithmetic policy (process-wide; initial value from the environment variable TAMGCN_SPLIT_BF16, default 1):
+ *   0  exact fp32-input MFMA (v_mfma_f32_16x16x4_f32) in every GEMM;
+ *   1  as 0 in the forward; weight-gradient GEMMs and the data-gradient GEMMs into >= 128 channels run as a 2-term
+ *      bf16 split (three v_mfma_f32_16x16x32_bf16, ~4.5e-6 relative error): their results never feed an activation;
+ *   2  as 1, and the forward x3 GEMM of the fused CTRGC kernel also as a 2-term split (gradient parity relaxed).
+ * Takes effect for launches issued after the call; not a stream operation. */
+int         tamgcn_get_split_mode(void);
+int         tamgcn_set_split_mode(int mode);
 /* bytes of LDS the CTRGC kernels need for (S subsets, V joints, R rel-channels);
  * <0 if the shape is unsupported.  Lets the host fail early and loudly. */
 int         tamgcn_ctrgc_lds_bytes(int S, int V, int R);
@@ -282,6 +290,23 @@ int tamgcn_head_pool_bwd(const float* dpooled, int N, int C, int T, int V, int M
 int tamgcn_head_fc_fwd(const float* pooled, const float* W, const float* b, int N, int C, int K, float* logits, void* stream);
 int tamgcn_head_fc_bwd(const float* dlogits, const float* pooled, const float* W, int N, int C, int K,
                        float* dW, float* db, float* dpooled, void* stream);
+
+/* ---- input side: skeleton streams and the feeder's per-sample transform ----------------------
+ * _stream_derive  the other three inputs of the 4-stream recipe from a joint batch x (N, C, T, V, M) resident in HBM:
+ *                 mode 1 bone        out[.., v, m] = x[.., v, m] - x[.., parent[v], m]   (reference feeder/feeder_nucla_gcn.py:27-28,
+ *                                    119-123: pair (v1, v2) of self.bone = (v + 1, parent[v] + 1); the pair (3, 3) gives 0)
+ *                 mode 2 motion      out[:, :, t] = x[:, :, t + 1] - x[:, :, t], last frame 0          (:124-127)
+ *                 mode 3 bone-motion motion of bone (upstream CTR-GCN's fourth stream; the reference feeder's `elif`
+ *                                    collapses a 'bone_motion' label path to bone -- stated in DESIGN.md)
+ * _feeder_transform  reference feeder/feeder_nucla_gcn.py:85-130 for N ragged clips at once, fp64 arithmetic as numpy's:
+ *                 raw (sum L_n, V, 3) fp64 with frame offsets [N + 1]; centre on joint `center_joint` of frame 0 (:98-99),
+ *                 p' = p . rot[n] (3 x 3 row-major view matrix Ry.Rx.S of :75-83; identity on the val path), per-coordinate
+ *                 min-max to [-1, 1] over the whole clip (:102-105), gather frames idx[n][time_steps] (:108-117: the host
+ *                 draws / computes the indices exactly as the reference does), stream `mode` (0 joint, 1..3 as above),
+ *                 out (N, 3, time_steps, V, 1) fp32 (:129-130, :154). */
+int tamgcn_stream_derive(const float* x, int N, int C, int T, int V, int M, const int* parent, int mode, float* out, void* stream);
+int tamgcn_feeder_transform(const double* raw, const long long* offsets, const double* rot, const int* idx, const int* parent,
+                            int N, int V, int time_steps, int center_joint, int mode, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -59,6 +59,8 @@ SIGNATURES = {
     'tamgcn_last_error': (C.c_char_p, []),
     'tamgcn_last_kernel': (C.c_char_p, []),
     'tamgcn_ctrgc_lds_bytes': (_i, [_i, _i, _i]),
+    'tamgcn_get_split_mode': (_i, []),
+    'tamgcn_set_split_mode': (_i, [_i]),
     'tamgcn_conv_nparts': (_i, [C.POINTER(ConvDesc)]),
     'tamgcn_conv': (_i, [C.POINTER(ConvDesc), _p]),
     'tamgcn_wgrad_max_split': (_i, [C.POINTER(WgradDesc)]),
@@ -89,6 +91,8 @@ SIGNATURES = {
     'tamgcn_add_act_fwd': (_i, [_SP, _SP, _i, _i, _i, _i, _i, _p, _p]),
     'tamgcn_add_act_bwd': (_i, [_p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
     'tamgcn_apply': (_i, [_SP, _i, _i, _i, _i, _p, _i, _i, _p]),
+    'tamgcn_stream_derive': (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _p, _p]),
+    'tamgcn_feeder_transform': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
 }
 
 

@@ -35,6 +35,19 @@ int tamgcn_split_mode(void);                     // TAMGCN_SPLIT_BF16: 0 = exact
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: the guard is a bit per device
+// ordinal (nn.DataParallel drives several devices from one process), not a process-wide flag.  Not a stream operation.
+typedef unsigned long long tg_devmask;
+static inline void tg_allow_lds(const void* fn, size_t bytes, tg_devmask* done) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const tg_devmask bit = 1ull << (dev & 63);
+    if (!(__atomic_load_n(done, __ATOMIC_RELAXED) & bit)) {
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        __atomic_fetch_or(done, bit, __ATOMIC_RELAXED);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // device side: fused operand prologue  value = act(c1*x1 + c2*x2 + c0)
 // ---------------------------------------------------------------------------

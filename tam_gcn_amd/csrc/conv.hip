@@ -1051,9 +1051,9 @@ extern "C" int tamgcn_conv(const tamgcn_conv_desc* d, void* stream) {
     if (big) {
         const int nmt = ceil_div(d->M, GS_BMT);
         const unsigned nblk = (unsigned)(d->N * p.ntt * nmt);
-        static bool fs = false;
+        static tg_devmask fs = 0;
         const size_t lds = sizeof(float) * ((size_t)GS_NST * (GS_BK * G_PBMAX + GS_BK * GS_BMT) + 3 * (size_t)d->K + 2 * 4 * BM);
-        if (!fs) { (void)hipFuncSetAttribute((const void*)conv1x1_glds_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); fs = true; }
+        tg_allow_lds((const void*)conv1x1_glds_split_kernel, 160 * 1024, &fs);
         TG_CHECK(lds <= 160 * 1024, "tamgcn_conv: K=%d too large for the split data-gradient kernel", d->K);
         hipLaunchKernelGGL(conv1x1_glds_split_kernel, dim3(nblk), dim3(G_NT), lds, (hipStream_t)stream, a, p.ntt, nmt);
         tamgcn_note_kernel("conv1x1_glds_split_kernel");
@@ -1061,15 +1061,15 @@ extern "C" int tamgcn_conv(const tamgcn_conv_desc* d, void* stream) {
         const int nmt = ceil_div(d->M, G_BMT);
         const unsigned nblk = (unsigned)(d->N * p.ntt * nmt);
         if (d->src.x2) {
-            static bool f2 = false;
+            static tg_devmask f2 = 0;
             const size_t lds = glds_lds_bytes<2, 8>(d->K);
-            if (!f2) { (void)hipFuncSetAttribute((const void*)conv1x1_glds_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); f2 = true; }
+            tg_allow_lds((const void*)conv1x1_glds_kernel<2, 8>, 160 * 1024, &f2);
             hipLaunchKernelGGL((conv1x1_glds_kernel<2, 8>), dim3(nblk), dim3(G_NT), lds, (hipStream_t)stream, a, p.ntt, nmt);
             tamgcn_note_kernel("conv1x1_glds_kernel<2, 8>");
         } else {
-            static bool f1 = false;
+            static tg_devmask f1 = 0;
             const size_t lds = glds_lds_bytes<1, 16>(d->K);
-            if (!f1) { (void)hipFuncSetAttribute((const void*)conv1x1_glds_kernel<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); f1 = true; }
+            tg_allow_lds((const void*)conv1x1_glds_kernel<1, 16>, 160 * 1024, &f1);
             hipLaunchKernelGGL((conv1x1_glds_kernel<1, 16>), dim3(nblk), dim3(G_NT), lds, (hipStream_t)stream, a, p.ntt, nmt);
             tamgcn_note_kernel("conv1x1_glds_kernel<1, 16>");
         }
@@ -1560,8 +1560,8 @@ static int launch_wgrad_glds(WgradArgs& a, hipStream_t s) {
     // a third stage only where it does not cost the second workgroup per CU
     constexpr int NST = (2 * STAGE <= 80 * 1024 && 3 * STAGE > 80 * 1024) ? 2 : W_NST;
     const size_t lds = NST * STAGE;
-    static bool flag = false;
-    if (!flag) { (void)hipFuncSetAttribute((const void*)wgrad_glds_kernel<WMT, WKT, NY, NX, SPL, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); flag = true; }
+    static tg_devmask flag = 0;
+    tg_allow_lds((const void*)wgrad_glds_kernel<WMT, WKT, NY, NX, SPL, NST>, 160 * 1024, &flag);
     a.n_per = ceil_div(a.N * (int)(((long long)a.T_out * a.V) / W_PC), a.nsplit);   // chunks per split
     const int ntk = ceil_div(a.K, BKW), ntm = ceil_div(a.M, BMW);
     hipLaunchKernelGGL((wgrad_glds_kernel<WMT, WKT, NY, NX, SPL, NST>), dim3((unsigned)(ntk * ntm * a.nsplit)), dim3(W_NT), lds, s, a, ntk, ntm);

@@ -954,16 +954,13 @@ static int fill_args(const tamgcn_ctrgc_desc* d, const CtrgcPlan& p, CtrgcArgs* 
 static unsigned grid_blocks(const CtrgcArgs& a) { return 8u * (unsigned)ceil_div(a.N, 8) * (unsigned)a.nct; }
 
 template <typename K>
-static void allow_lds(K kernel, size_t lds, bool* done) {
-    if (!*done) {   // once per instantiation; not a stream operation
-        (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        *done = true;
-    }
+static void allow_lds(K kernel, size_t lds, tg_devmask* done) {   // once per instantiation and device
+    tg_allow_lds((const void*)kernel, lds, done);
 }
 
 #define CTRGC_LAUNCH(KERNEL, GEO, ST_, FLAG, ...)                                                              \
     do {                                                                                                       \
-        static bool FLAG = false;                                                                              \
+        static tg_devmask FLAG = 0;                                                                            \
         allow_lds(KERNEL<GEO, ST_>, p.lds, &FLAG);   /* exact size: static LDS comes on top */                                                        \
         hipLaunchKernelGGL((KERNEL<GEO, ST_>), dim3(grid_blocks(a)), dim3(GEO::NT), p.lds, (hipStream_t)stream, __VA_ARGS__); \
         tamgcn_note_kernel(#KERNEL "<Geo<%d, %d, %d>, %d>", GEO::V, GEO::TB, GEO::NTQ, ST_);                           \
@@ -996,11 +993,11 @@ extern "C" int tamgcn_ctrgc_build_e(const tamgcn_ctrgc_desc* d, float* E, void* 
     a.pq = d->pq; a.w4 = d->w4; a.b4 = d->b4; a.A = d->A; a.alpha = d->alpha; a.E = E;
     const size_t lds = sizeof(float) * ((size_t)(16 + d->R) * d->V * d->V + 2 * (size_t)d->R * d->V);
     if (d->V == 20) {
-        static bool f = false;
+        static tg_devmask f = 0;
         allow_lds(ctrgc_E_kernel<20>, 160 * 1024, &f);
         hipLaunchKernelGGL((ctrgc_E_kernel<20>), dim3(d->N * d->S), dim3(512), lds, (hipStream_t)stream, a);
     } else {
-        static bool f = false;
+        static tg_devmask f = 0;
         allow_lds(ctrgc_E_kernel<25>, 160 * 1024, &f);
         hipLaunchKernelGGL((ctrgc_E_kernel<25>), dim3(d->N * d->S), dim3(512), lds, (hipStream_t)stream, a);
     }

@@ -412,11 +412,8 @@ __global__ __launch_bounds__(512) void ctrgc_de_tail_kernel(const TailArgs a) {
 }
 
 template <typename K>
-void allow_lds(K kernel, size_t lds, bool* done) {
-    if (!*done && lds > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        *done = true;
-    }
+void allow_lds(K kernel, size_t lds, tg_devmask* done) {       // once per instantiation and device
+    if (lds > 48 * 1024) tg_allow_lds(reinterpret_cast<const void*>(kernel), lds, done);
 }
 
 template <int V>
@@ -427,7 +424,7 @@ size_t tail_lds(int R, int RT) { return sizeof(float) * ((size_t)(R + 16) * tail
 #define DE_ACC_CASE(VV_, SS_)                                                                                          \
     if (d->V == VV_ && d->S == SS_) {                                                                                  \
         using G = AccGeo<VV_, SS_>;                                                                                    \
-        static bool flag = false;                                                                                      \
+        static tg_devmask flag = 0;                                                                                    \
         allow_lds(ctrgc_de_acc_kernel<G>, G::LDS, &flag);                                                              \
         hipLaunchKernelGGL((ctrgc_de_acc_kernel<G>), dim3(d->N * (d->Cout / G::CA)), dim3(G::NT), G::LDS, (hipStream_t)stream, \
                            d->N, d->Cout, d->T, x3, make_src(*dy), dE);                                                \
@@ -448,7 +445,7 @@ extern "C" int tamgcn_ctrgc_bwd_de_acc(const tamgcn_ctrgc_desc* d, const tamgcn_
 
 #define DE_TAIL_CASE(VV_, RT_)                                                                                         \
     if (d->V == VV_ && rt == RT_) {                                                                                    \
-        static bool flag = false;                                                                                      \
+        static tg_devmask flag = 0;                                                                                    \
         const size_t lds = tail_lds<VV_>(d->R, RT_);                                                                   \
         allow_lds(ctrgc_de_tail_kernel<VV_, RT_>, tail_lds<VV_>(32, 2), &flag);                                        \
         hipLaunchKernelGGL((ctrgc_de_tail_kernel<VV_, RT_>), dim3(d->N * d->S * groups), dim3(512), lds, (hipStream_t)stream, a); \

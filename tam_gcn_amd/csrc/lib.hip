@@ -26,12 +26,22 @@ extern "C" int tamgcn_version(void) { return TAMGCN_VERSION; }
 extern "C" const char* tamgcn_last_error(void) { return g_err; }
 
 // Split-fp32 (3 x bf16 MFMA) policy for the GEMM kernels, read once from the environment.
+static int g_split_mode = -1;
+
 int tamgcn_split_mode(void) {
-    static int mode = -1;
+    int mode = __atomic_load_n(&g_split_mode, __ATOMIC_RELAXED);
     if (mode < 0) {
         const char* e = getenv("TAMGCN_SPLIT_BF16");
         mode = e ? atoi(e) : 1;
         if (mode < 0 || mode > 2) mode = 1;
+        __atomic_store_n(&g_split_mode, mode, __ATOMIC_RELAXED);
     }
     return mode;
+}
+
+extern "C" int tamgcn_get_split_mode(void) { return tamgcn_split_mode(); }
+extern "C" int tamgcn_set_split_mode(int mode) {
+    TG_CHECK(mode >= 0 && mode <= 2, "tamgcn_set_split_mode: mode %d outside 0..2", mode);
+    __atomic_store_n(&g_split_mode, mode, __ATOMIC_RELAXED);
+    return 0;
 }

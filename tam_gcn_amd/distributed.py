@@ -114,12 +114,20 @@ class FlatGradBucket:
             p.grad = v
         return self.flat
 
-    def all_reduce_mean(self, group=None):
-        """Sum over ranks / world size: the gradient of the mean loss over the global batch
-        (equal shards), matching DataParallel's loss over the gathered batch."""
+    def all_reduce_mean(self, group=None, local_n=None, global_n=None):
+        """Gradient of the mean loss over the GLOBAL batch, as DataParallel's loss over the gathered batch gives it
+        (processor/io.py:86-87).  Equal shards (the default): sum over ranks / world size.  Unequal shards
+        (shard_batch() with n_global % world != 0): pass this rank's ``local_n`` and the ``global_n``; every rank's
+        mean-loss gradient is weighted by local_n / global_n before the sum."""
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-            self.flat.div_(dist.get_world_size(group))
+            if local_n is not None:
+                if not global_n:
+                    raise ValueError('all_reduce_mean: local_n needs global_n')
+                self.flat.mul_(float(local_n) / float(global_n))
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+                self.flat.div_(dist.get_world_size(group))
         return self.flat
 
 

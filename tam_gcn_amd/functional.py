@@ -11,6 +11,7 @@ Reference arithmetic being reproduced: models/ctrgcn.py:52-69 (TemporalConv),
 """
 import contextlib
 import os
+import threading
 
 import torch
 
@@ -25,6 +26,7 @@ from .ops import S, RELU
 # wait_stream (event record + wait), which HIP graph capture turns into parallel branches.
 # ---------------------------------------------------------------------------
 _SIDE = {}
+_SIDE_LOCK = threading.Lock()
 USE_SIDE_STREAMS = os.environ.get('TAMGCN_SIDE_STREAMS', '1') != '0'
 # keep x3 = conv3(x) from the forward for the backward (3 x one activation per block, ~3 GB at batch 256)
 # instead of recomputing the GEMM there; TAMGCN_KEEP_X3=0 trades the memory back for time
@@ -39,9 +41,11 @@ class Fork:
 
     def __init__(self, device, k=2):
         self.main = torch.cuda.current_stream(device)
-        key = (device.index, k)
+        key = (device.index, k)                              # per device: nn.DataParallel drives each device from ONE thread at a time
         if key not in _SIDE:
-            _SIDE[key] = [torch.cuda.Stream(device) for _ in range(k)]
+            with _SIDE_LOCK:
+                if key not in _SIDE:
+                    _SIDE[key] = [torch.cuda.Stream(device) for _ in range(k)]
         self.side = _SIDE[key] if USE_SIDE_STREAMS else []
         self.used = set()
 

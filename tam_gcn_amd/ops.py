@@ -3,6 +3,7 @@ output allocation through torch's caching allocator, the current HIP stream.
 No arithmetic happens here."""
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -21,7 +22,7 @@ def _ptr(t):
         return None
     if not (t.is_cuda and t.is_contiguous()):
         raise RuntimeError('tam_gcn_amd: expected a contiguous HIP (cuda) tensor; there is no CPU path')
-    if t.dtype not in (torch.float32, torch.int64):
+    if t.dtype not in (torch.float32, torch.int64, torch.int32, torch.float64):
         raise RuntimeError(f'tam_gcn_amd: unsupported dtype {t.dtype}')
     return t.data_ptr()
 
@@ -126,16 +127,24 @@ def wgrad(gy, src, M, K, KT=1, dil=1, stride=1, pad=0, rows=None):
 class ReduceBatch:
     """with ReduceBatch(): every reduce_sum() inside only registers its slabs and returns the (not yet filled) output;
     ONE tamgcn_reduce_multi launch on the stream current at exit fills them all.  The caller guarantees that nothing
-    inside reads a reduced value and that every producer has been joined into that stream before the exit."""
-    _active = None
+    inside reads a reduced value and that every producer has been joined into that stream before the exit.
+
+    The active batch is per THREAD: nn.DataParallel (the reference's multi-GPU mode, processor/io.py:86-87) runs one
+    autograd thread per device and ctypes / torch calls release the GIL, so a process-global would let one device's
+    reductions land in another device's batch."""
+    _tls = threading.local()
+
+    @staticmethod
+    def active():
+        return getattr(ReduceBatch._tls, 'active', None)
 
     def __enter__(self):
-        self.items, self.prev = [], ReduceBatch._active
-        ReduceBatch._active = self
+        self.items, self.prev = [], ReduceBatch.active()
+        ReduceBatch._tls.active = self
         return self
 
     def __exit__(self, *exc):
-        ReduceBatch._active = self.prev
+        ReduceBatch._tls.active = self.prev
         if self.items and exc[0] is None:
             arr = (ReduceDesc * len(self.items))()
             for i, (part, nsplit, stride, off, count, scale, acc, out) in enumerate(self.items):
@@ -171,7 +180,7 @@ def reduce_sum(part, nsplit, scale=1.0, out=None, accumulate=False, chunks=None)
 
 
 def _reduce_piece(part, nsplit, stride, off, count, scale, out, accumulate=False):
-    rb = ReduceBatch._active
+    rb = ReduceBatch.active()
     if rb is not None:
         rb.items.append((part, nsplit, stride, off, count, scale, accumulate, out))   # keeps `part` alive until the launch
         return
@@ -433,3 +442,29 @@ def head_fc_bwd(dlogits, pooled, W):
     _lib.check(_lib_().tamgcn_head_fc_bwd(_ptr(dlogits), _ptr(pooled), _ptr(W), N, C_, K, _ptr(dW), _ptr(db), _ptr(dpooled), _stream()),
                'tamgcn_head_fc_bwd')
     return dW, db, dpooled
+
+
+# ---------------------------------------------------------------------------
+# input side: skeleton streams, the feeder's per-sample transform
+STREAM_MODES = {'joint': 0, 'bone': 1, 'motion': 2, 'joint_motion': 2, 'bone_motion': 3}
+
+
+def stream_derive(x5, parent, mode):
+    """x5 (N, C, T, V, M) joint clips -> the 'bone' / 'motion' / 'bone_motion' stream (same shape); parent int32 [V]."""
+    N, C_, T, V, M = x5.shape
+    m = STREAM_MODES[mode] if isinstance(mode, str) else int(mode)
+    if m == 0:
+        return x5
+    out = torch.empty_like(x5)
+    _lib.check(_lib_().tamgcn_stream_derive(_ptr(x5), N, C_, T, V, M, _ptr(parent), m, _ptr(out), _stream()), 'tamgcn_stream_derive')
+    return out
+
+
+def feeder_transform(raw, offsets, rot, idx, parent, V, time_steps, center_joint, mode):
+    """raw (sum L, V, 3) fp64, offsets int64 [N+1], rot fp64 (N, 3, 3), idx int32 (N, time_steps) -> (N, 3, time_steps, V, 1) fp32."""
+    N = offsets.numel() - 1
+    m = STREAM_MODES[mode] if isinstance(mode, str) else int(mode)
+    out = torch.empty(N, 3, time_steps, V, 1, device=raw.device, dtype=torch.float32)
+    _lib.check(_lib_().tamgcn_feeder_transform(_ptr(raw), _ptr(offsets), _ptr(rot), _ptr(idx), _ptr(parent), N, V, time_steps,
+                                               center_joint, m, _ptr(out), _stream()), 'tamgcn_feeder_transform')
+    return out

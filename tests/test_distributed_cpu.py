@@ -114,3 +114,104 @@ def test_param_arena_zero_copy_packing_and_flat_sgd():
     assert arena.intact()
     m.load_state_dict(before)                                    # in-place copies keep the views
     assert arena.intact() and torch.equal(m.fc.weight, before['fc.weight'])
+
+
+# ---------------------------------------------------------------------------
+# The real Model + ParamArena + flat bucket + flat SGD over two gloo ranks with UNEQUAL shards (5 + 3 clips).  The
+# HIP forward cannot run here, so each rank's gradients come from the CPU oracle on its shard (test infrastructure);
+# everything after the backward is the product's distributed code.
+# ---------------------------------------------------------------------------
+_MARGS = dict(num_class=10, num_point=20, num_person=1, graph='graph.ucla.Graph', graph_args=dict(labeling_mode='spatial'))
+
+
+def _oracle_grads(model, x, lab):
+    from oracle import ctrgcn_oracle as O
+    sd = O.clone_state(model.state_dict(), requires_grad=True)
+    loss = torch.nn.functional.cross_entropy(O.model_forward(x, sd, 20, training=True), lab)
+    loss.backward()
+    return {k: sd[k].grad for k, _ in model.named_parameters()}
+
+
+def _model_worker(rank, world, port, out):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden'))
+    from params import fill_state_, make_input, make_labels
+    from tam_gcn_amd.distributed import ParamArena
+    from tam_gcn_amd.models.ctrgcn import Model
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    m = Model(**_MARGS)
+    fill_state_(m.state_dict(), seed=50 + rank)              # replicas start different on purpose
+    arena = ParamArena(m)
+    broadcast_state(m, src=0)
+    bucket = arena.grad_bucket()
+    opt = SGDNesterov(arena.params, lr=0.01, momentum=0.9, weight_decay=1e-4, arena=arena, bucket=bucket)
+    n_global = 8
+    X, Y = make_input((n_global, 3, 8, 20, 1), seed=9), make_labels(n_global, 10, seed=10)
+    lo, hi = (0, 5) if rank == 0 else (5, 8)                   # unequal on purpose
+    bucket.zero()
+    grads = _oracle_grads(m, X[lo:hi], Y[lo:hi])
+    for k, p in m.named_parameters():
+        p.grad = grads[k].clone()
+    bucket.pack()
+    bucket.all_reduce_mean(local_n=hi - lo, global_n=n_global)
+    out[f'g{rank}'] = bucket.flat.clone()
+    opt.step()
+    out[rank] = arena.flat.clone()
+    assert arena.intact()
+    dist.destroy_process_group()
+
+
+def test_two_rank_real_model_arena_uneven_shards():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden'))
+    from params import fill_state_, make_input, make_labels
+    from tam_gcn_amd.distributed import ParamArena
+    from tam_gcn_amd.models.ctrgcn import Model
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_model_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert torch.equal(out[0], out[1])                          # replicas identical after the step
+    assert torch.equal(out['g0'], out['g1'])
+    # single-process emulation: per-shard gradients (per-replica BatchNorm statistics, as nn.DataParallel computes them)
+    # weighted by shard size = the gradient of the mean loss over the 8 clips
+    m = Model(**_MARGS)
+    fill_state_(m.state_dict(), seed=50)
+    arena = ParamArena(m)
+    bucket = arena.grad_bucket()
+    X, Y = make_input((8, 3, 8, 20, 1), seed=9), make_labels(8, 10, seed=10)
+    g0, g1 = _oracle_grads(m, X[:5], Y[:5]), _oracle_grads(m, X[5:], Y[5:])
+    for k, p in m.named_parameters():
+        p.grad = (5 * g0[k] + 3 * g1[k]) / 8
+    bucket.pack()
+    # (thread counts differ between the workers and this process: fp32 summation order, ~1e-6 of the gradient scale)
+    assert torch.allclose(out['g0'], bucket.flat, rtol=1e-4, atol=2e-6 * float(bucket.flat.abs().max()))
+    opt = SGDNesterov(arena.params, lr=0.01, momentum=0.9, weight_decay=1e-4, arena=arena, bucket=bucket)
+    opt.step()
+    assert torch.allclose(out[0], arena.flat, rtol=1e-5, atol=1e-6)
+
+
+def test_bench_self_launches_two_ranks_rehearsal():
+    """`python bench.py --gpus 2` outside a launcher must start its own two ranks and print ONE JSON line with n_gpus 2
+    (the driver invokes it exactly like that).  TAMGCN_BENCH_REHEARSAL=1 runs the control flow on CPU tensors over gloo."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['TAMGCN_BENCH_REHEARSAL'] = '1'
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout.decode()
+    js = json.loads(lines[0])
+    assert js['n_gpus'] == 2 and js['steps'] == 3 and js['config']['rehearsal'] is True and js['value'] is None
+    assert js['config']['global_batch'] == 512 and js['scaling'] == 'weak'
+    # a launcher environment that disagrees with --gpus is an error, not silently ignored
+    env2 = dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    r2 = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'], env=env2, stdout=subprocess.PIPE,
+                        stderr=subprocess.PIPE, timeout=600)
+    assert r2.returncode != 0 and b'WORLD_SIZE=1' in r2.stderr
