@@ -35,7 +35,7 @@ extern "C" {
 
 #define TAMGCN_VERSION 100          /* 0.1.0 */
 #define TAMGCN_MAX_SUBSETS 3
-#define TAMGCN_MAX_V 32             /* joints supported by the LDS-resident CTRGC tiles */
+#define TAMGCN_MAX_V 32             /* joints supported by the LDS-resident CTRGC tiles (V in {20, 25}); V in {32, 64}: tamgcn_ctrgc_tiled_* */
 
 typedef struct tamgcn_src {
     const float* x1;
@@ -62,7 +62,8 @@ const char* tamgcn_last_kernel(void);
  * Takes effect for launches issued after the call; not a stream operation. */
 int         tamgcn_get_split_mode(void);
 int         tamgcn_set_split_mode(int mode);
-/* bytes of LDS the CTRGC kernels need for (S subsets, V joints, R rel-channels);
+/* bytes of LDS the CTRGC kernels need for (S subsets, V joints, R rel-channels): the fused LDS-resident family for
+ * V in {20, 25}, the tiled large-skeleton family (tamgcn_ctrgc_tiled_*) for V in {32, 64};
  * <0 if the shape is unsupported.  Lets the host fail early and loudly. */
 int         tamgcn_ctrgc_lds_bytes(int S, int V, int R);
 
@@ -230,6 +231,27 @@ int tamgcn_ctrgc_bwd_de_acc(const tamgcn_ctrgc_desc* d, const tamgcn_src* dy, co
 int tamgcn_ctrgc_bwd_de_tail(const tamgcn_ctrgc_desc* d, const float* dE,
                              float* dA_part, float* dw4_part, float* db4_part,
                              float* dalpha_part, float* dpq, int groups, void* stream);
+
+/* ---- CTRGC for large skeletons (V in {32, 64}; BASELINE.json configs[4]: V = 64, T = 512, C = 256) ---------------
+ * One channel's topology E is 3*V*V floats (48 KB at V = 64): the fused LDS-resident kernels above do not apply
+ * (tamgcn_ctrgc_lds_bytes < 0).  The same arithmetic (reference models/ctrgcn.py:172-177, V-generic) then runs as
+ *   x3 = W3 x + b3                  tamgcn_conv (M = S*Cout), kept in HBM: (N, S*Cout, T, V)
+ *   _tiled_build_e                  E (N, S, Cout, V, V), workgroup = (n, s, 512/V rows u)
+ *   _tiled_agg_fwd                  y[n,c,t,u] = sum_s sum_v x3_s[n,c,t,v] E_s[n,c,u,v] on MFMA; stats_part [2][Cout][N] optional
+ *   _tiled_agg_bwd                  dx3[n,s*Cout+c,t,v] = sum_u dy(n,c,t,u) E_s[n,c,u,v]; db3_part [N][S*Cout] optional
+ *   _tiled_de_acc                   dE (N, S, Cout, V, V) = sum_t dy(n,c,t,u) x3[n,s*Cout+c,t,v]
+ *   _tiled_de_tail                  dE -> dA_part [N][S][V][V], dw4_part [N*NUC][S][Cout][R], db4_part [N*NUC][S][Cout],
+ *                                   dalpha_part [N*S*NUC], dpq [NUC][S*2*R][N][V] (sum the slabs over NUC);
+ *                                   NUC = tamgcn_ctrgc_tiled_chunks(V) row chunks of E per (n, s).  R <= 32.
+ * d->x, d->w3, d->b3, d->E are not read by these entry points (E and x3 are explicit arguments). */
+int tamgcn_ctrgc_tiled_supported(int V);
+int tamgcn_ctrgc_tiled_chunks(int V);
+int tamgcn_ctrgc_tiled_build_e(const tamgcn_ctrgc_desc* d, float* E, void* stream);
+int tamgcn_ctrgc_tiled_agg_fwd(const tamgcn_ctrgc_desc* d, const float* x3, const float* E, float* y, float* stats_part, void* stream);
+int tamgcn_ctrgc_tiled_agg_bwd(const tamgcn_ctrgc_desc* d, const tamgcn_src* dy, const float* E, float* dx3, float* db3_part, void* stream);
+int tamgcn_ctrgc_tiled_de_acc(const tamgcn_ctrgc_desc* d, const tamgcn_src* dy, const float* x3, float* dE, void* stream);
+int tamgcn_ctrgc_tiled_de_tail(const tamgcn_ctrgc_desc* d, const float* dE, float* dA_part, float* dw4_part, float* db4_part,
+                               float* dalpha_part, float* dpq, void* stream);
 
 /* ------------------------------------------------------------------------
  * Element-wise block epilogues and their backward reductions.

@@ -82,6 +82,13 @@ SIGNATURES = {
     'tamgcn_ctrgc_bwd_de': (_i, [C.POINTER(CtrgcDesc), _SP, _p, _p, _p, _p, _p, _p]),
     'tamgcn_ctrgc_bwd_de_acc': (_i, [C.POINTER(CtrgcDesc), _SP, _p, _p, _p]),
     'tamgcn_ctrgc_bwd_de_tail': (_i, [C.POINTER(CtrgcDesc), _p, _p, _p, _p, _p, _p, _i, _p]),
+    'tamgcn_ctrgc_tiled_supported': (_i, [_i]),
+    'tamgcn_ctrgc_tiled_chunks': (_i, [_i]),
+    'tamgcn_ctrgc_tiled_build_e': (_i, [C.POINTER(CtrgcDesc), _p, _p]),
+    'tamgcn_ctrgc_tiled_agg_fwd': (_i, [C.POINTER(CtrgcDesc), _p, _p, _p, _p, _p]),
+    'tamgcn_ctrgc_tiled_agg_bwd': (_i, [C.POINTER(CtrgcDesc), _SP, _p, _p, _p, _p]),
+    'tamgcn_ctrgc_tiled_de_acc': (_i, [C.POINTER(CtrgcDesc), _SP, _p, _p, _p]),
+    'tamgcn_ctrgc_tiled_de_tail': (_i, [C.POINTER(CtrgcDesc), _p, _p, _p, _p, _p, _p, _p]),
     'tamgcn_ew_nparts': (_i, [_i, _i, _i, _i]),
     'tamgcn_gcn_tail_fwd': (_i, [_SP, _SP, _SP, _i, _i, _i, _i, _p, _p]),
     'tamgcn_gcn_tail_bwd': (_i, [_p, _p, _SP, _p, _i, _i, _i, _i, _p, _p, _p, _p]),

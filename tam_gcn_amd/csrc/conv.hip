@@ -1714,10 +1714,16 @@ extern "C" int tamgcn_wgrad(const tamgcn_wgrad_desc* d, void* stream) {
             else if (wmt == 2 && wkt == 4) rc = launch_wgrad<1, 2, 4>(a, s);
             else rc = launch_wgrad<1, 4, 4>(a, s);
             break;
-        case 3: rc = wmt == 1 ? launch_wgrad<3, 1, 1>(a, s) : launch_wgrad<3, 2, 2>(a, s); break;
+        // k x 1 kernels: when the preferred tile's line buffer (frames + temporal halo, V joints each) does not fit --
+        // V = 64 -- fall back to the next smaller tile instead of refusing
+        case 3:
+            rc = wmt == 1 ? -1 : launch_wgrad<3, 2, 2>(a, s);
+            if (rc == -1) rc = launch_wgrad<3, 1, 1>(a, s);
+            break;
         case 5:
-            if (d->M <= 16 && d->K <= 16 && d->V % 4 == 0) rc = launch_wgrad<5, 1, 1, true>(a, s);
-            else rc = wmt == 1 ? launch_wgrad<5, 1, 1>(a, s) : launch_wgrad<5, 2, 2>(a, s);
+            rc = (d->M <= 16 && d->K <= 16 && d->V % 4 == 0) ? launch_wgrad<5, 1, 1, true>(a, s) : -1;
+            if (rc == -1 && wmt != 1) rc = launch_wgrad<5, 2, 2>(a, s);
+            if (rc == -1) rc = launch_wgrad<5, 1, 1>(a, s);
             break;
         case 9: rc = launch_wgrad<9, 1, 1>(a, s); break;
         default: tamgcn_set_error("tamgcn_wgrad: kernel size %d not instantiated (1,3,5,9)", d->KT); return -1;

@@ -976,10 +976,11 @@ static void allow_lds(K kernel, size_t lds, tg_devmask* done) {   // once per in
 
 }  // namespace
 
+int tamgcn_ctrgc_tiled_lds_bytes(int S, int V, int R);      // ctrgc_tiled.hip: the large-skeleton family (V in {32, 64})
+
 extern "C" int tamgcn_ctrgc_lds_bytes(int S, int V, int R) {
-    (void)R;
     CtrgcPlan p;
-    if (plan_ctrgc(S, V, &p)) return -1;
+    if (plan_ctrgc(S, V, &p)) return tamgcn_ctrgc_tiled_lds_bytes(S, V, R);
     return (int)p.lds;
 }
 

@@ -143,7 +143,7 @@ def gcn_forward(x, P, training, save):
     xbar = ops.tmean(xs, Cin)                                             # (Cin, N, V)
     pq, _ = ops.conv(S(xbar.view(1, Cin, N, V)), K=Cin, w=P.W12, bias=P.B12, M=S_ * 2 * R)
     pq = pq.view(S_ * 2 * R, N, V)
-    E = ops.ctrgc_build_E(xs, pq, P.W3, P.B3, P.W4, P.B4, P.PA, P.alpha, Cin, Cout, S_, R) if (GLOBAL_E and R <= 32) else None
+    E = ops.ctrgc_build_E(xs, pq, P.W3, P.B3, P.W4, P.B4, P.PA, P.alpha, Cin, Cout, S_, R) if ((GLOBAL_E or ops.ctrgc_tiled(V)) and R <= 32) else None
     y_pre, ypart, x3 = ops.ctrgc_fwd(xs, pq, P.W3, P.B3, P.W4, P.B4, P.PA, P.alpha, Cin, Cout, S_, R, stats=training,
                                      keep_x3=save and KEEP_X3, E=E)
     coef_y, save_y = _coef(Cout, x)

@@ -47,6 +47,22 @@ def _lib_():
     return _lib.load()
 
 
+# Kernels index one launch's tensors with 32-bit element offsets inside a sample block and refuse tensors of >= 2^32
+# elements; the V = 64, T = 512, C = 256 configuration at 256 clips has a 6.4e9-element x3.  Such calls are split over
+# the clip dimension N (clips are independent; every tensor is contiguous in n) into launches below this bound.
+CHUNK_ELEMS = int(os.environ.get('TAMGCN_CHUNK_ELEMS', str(2 ** 31 - 1)))
+
+
+def n_chunks(N, per_clip):
+    """[(n0, n1)] covering range(N) such that (n1 - n0) * per_clip <= CHUNK_ELEMS (at least one clip per chunk)."""
+    c = max(1, CHUNK_ELEMS // max(1, per_clip))
+    return [(i, min(N, i + c)) for i in range(0, N, c)]
+
+
+def _slice_src(src, n0, n1):
+    return S(src.x1[n0:n1], None if src.x2 is None else src.x2[n0:n1], src.coef, src.coff, src.act)
+
+
 def empty(*shape, like):
     return torch.empty(shape, device=like.device, dtype=torch.float32)
 
@@ -66,6 +82,15 @@ def conv(src, K, w, bias, M, KT=1, dil=1, stride=1, pad=0, wmode=0, up=1,
         y = empty(N, M, T_y, V, like=x)
     else:
         T_y = y.shape[2]
+    per_clip = max(x.shape[1] * T_in * V, y.shape[1] * T_y * V)
+    if N > 1 and N * per_clip > CHUNK_ELEMS:
+        if stats or mask is not None or aux is not None:
+            raise RuntimeError('tam_gcn_amd: a convolution over >= 2^31 elements cannot carry BatchNorm moments / a mask')
+        for n0, n1 in n_chunks(N, per_clip):
+            conv(_slice_src(src, n0, n1), K, w, bias, M, KT, dil, stride, pad, wmode, up, y=y[n0:n1], ycoff=ycoff, T_out=T_out,
+                 ostride=ostride, add1=None if add1 is None else add1[n0:n1], add2=None if add2 is None else add2[n0:n1],
+                 bcast=None if bcast is None else bcast[:, n0:n1].contiguous(), bcast_scale=bcast_scale)
+        return y, None
     d = ConvDesc()
     d.src = src.c()
     d.N, d.K, d.T_in, d.V = N, K, T_in, V
@@ -100,6 +125,8 @@ def wgrad(gy, src, M, K, KT=1, dil=1, stride=1, pad=0, rows=None):
     """Returns dW (M, K, KT, 1); with rows = [m0, m1, ...] (summing to M) a list of separate (m_i, K, KT, 1) tensors."""
     N, _, T_out, V = gy.x1.shape
     T_in = src.x1.shape[2]
+    per_clip = max(gy.x1.shape[1] * T_out * V, src.x1.shape[1] * T_in * V)
+    chunks = n_chunks(N, per_clip) if N * per_clip > CHUNK_ELEMS else [(0, N)]
     # same tile rule as wgrad_tile() in csrc/conv.hip: aim at ~4 resident workgroups per CU
     if KT == 1:
         bm, bk = (64 if M <= 64 else 128), (64 if K <= 64 else 128)
@@ -108,15 +135,24 @@ def wgrad(gy, src, M, K, KT=1, dil=1, stride=1, pad=0, rows=None):
     else:
         bm = bk = 32 if (M <= 32 and K <= 32) else 64
     tiles = ((M + bm - 1) // bm) * ((K + bk - 1) // bk)
-    d = WgradDesc()
-    d.gy, d.src = gy.c(), src.c()
-    d.N, d.M, d.K, d.T_in, d.T_out, d.V = N, M, K, T_in, T_out, V
-    d.KT, d.dil, d.stride, d.pad = KT, dil, stride, pad
     lib = _lib_()
-    nsplit = max(1, min(lib.tamgcn_wgrad_max_split(C.byref(d)), (WGRAD_BLOCKS + tiles - 1) // tiles))
+    descs = []
+    for n0, n1 in chunks:
+        d = WgradDesc()
+        g_, s_ = (gy, src) if len(chunks) == 1 else (_slice_src(gy, n0, n1), _slice_src(src, n0, n1))
+        d.gy, d.src = g_.c(), s_.c()
+        d.N, d.M, d.K, d.T_in, d.T_out, d.V = n1 - n0, M, K, T_in, T_out, V
+        d.KT, d.dil, d.stride, d.pad = KT, dil, stride, pad
+        descs.append((d, g_, s_))
+    per = max(1, (WGRAD_BLOCKS + tiles - 1) // tiles // len(chunks))
+    splits = [max(1, min(lib.tamgcn_wgrad_max_split(C.byref(d)), per)) for d, _, _ in descs]
+    nsplit = sum(splits)                                   # every chunk's partial slabs sit in ONE array: one reduction
     part = empty(nsplit, M, K, KT, like=gy.x1)
-    d.part, d.nsplit = _ptr(part), nsplit
-    _lib.check(lib.tamgcn_wgrad(C.byref(d), _stream()), 'tamgcn_wgrad')
+    off = 0
+    for (d, _, _), ns in zip(descs, splits):
+        d.part, d.nsplit = part.data_ptr() + 4 * off * M * K * KT, ns
+        _lib.check(lib.tamgcn_wgrad(C.byref(d), _stream()), 'tamgcn_wgrad')
+        off += ns
     if rows is not None:
         return reduce_sum(part, nsplit, chunks=[(m, K, KT, 1) for m in rows])
     if nsplit == 1:
@@ -154,7 +190,7 @@ class ReduceBatch:
         return False
 
 
-def reduce_sum(part, nsplit, scale=1.0, out=None, accumulate=False, chunks=None):
+def reduce_sum(part, nsplit, scale=1.0, out=None, accumulate=False, chunks=None, immediate=False):
     """part [nsplit][...] -> sum over the leading dim (deferred to the enclosing ReduceBatch, if any).
 
     chunks = list of shapes: the reduced vector is delivered as that many SEPARATE tensors (consecutive pieces), so that
@@ -175,12 +211,12 @@ def reduce_sum(part, nsplit, scale=1.0, out=None, accumulate=False, chunks=None)
         return outs
     if out is None:
         out = torch.empty(part.shape[1:], device=part.device, dtype=torch.float32)
-    _reduce_piece(part, nsplit, count, 0, count, scale, out, accumulate)
+    _reduce_piece(part, nsplit, count, 0, count, scale, out, accumulate, immediate)   # immediate: the value is read inside the batch
     return out
 
 
-def _reduce_piece(part, nsplit, stride, off, count, scale, out, accumulate=False):
-    rb = ReduceBatch.active()
+def _reduce_piece(part, nsplit, stride, off, count, scale, out, accumulate=False, immediate=False):
+    rb = None if immediate else ReduceBatch.active()
     if rb is not None:
         rb.items.append((part, nsplit, stride, off, count, scale, accumulate, out))   # keeps `part` alive until the launch
         return
@@ -235,13 +271,27 @@ def _ctrgc_desc(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, E=None):
     return d
 
 
+def ctrgc_tiled(V):
+    """True for the large-skeleton geometry (V in {32, 64}): x3 through the pointwise GEMM, aggregation on MFMA."""
+    return bool(_lib_().tamgcn_ctrgc_tiled_supported(int(V)))
+
+
 def ctrgc_build_E(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R):
     """E (N, S, Cout, V, V) for every channel, once per layer; hand it to ctrgc_fwd / ctrgc_bwd_dx3 (R <= 32)."""
     N, _, T, V = x.x1.shape
     d = _ctrgc_desc(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R)
     E = empty(N, S, Cout, V, V, like=x.x1)
-    _lib.check(_lib_().tamgcn_ctrgc_build_e(C.byref(d), _ptr(E), _stream()), 'tamgcn_ctrgc_build_e')
+    if ctrgc_tiled(V):
+        _lib.check(_lib_().tamgcn_ctrgc_tiled_build_e(C.byref(d), _ptr(E), _stream()), 'tamgcn_ctrgc_tiled_build_e')
+    else:
+        _lib.check(_lib_().tamgcn_ctrgc_build_e(C.byref(d), _ptr(E), _stream()), 'tamgcn_ctrgc_build_e')
     return E
+
+
+def _x3_gemm(x, w3, b3, Cin, Cout, S):
+    """x3 = conv3(x) of every subset as ONE pointwise GEMM: (N, S*Cout, T, V)."""
+    x3, _ = conv(x, K=Cin, w=w3, bias=b3.reshape(-1), M=S * Cout)
+    return x3
 
 
 def ctrgc_fwd(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, stats, keep_x3=False, E=None):
@@ -250,6 +300,23 @@ def ctrgc_fwd(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, stats, keep_x3=F
     d = _ctrgc_desc(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, E)
     y = empty(N, Cout, T, V, like=x.x1)
     part = empty(2, Cout, N, like=x.x1) if stats else None
+    if ctrgc_tiled(V):
+        if E is None:
+            E = ctrgc_build_E(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R)
+        x3 = _x3_gemm(x, w3, b3, Cin, Cout, S)
+        chunks = n_chunks(N, S * Cout * T * V)
+        parts = []
+        for n0, n1 in chunks:                              # one launch unless x3 has >= 2^31 elements
+            d.N = n1 - n0
+            pc = None
+            if stats:
+                pc = part if len(chunks) == 1 else empty(2, Cout, n1 - n0, like=x.x1)
+                parts.append(pc)
+            _lib.check(_lib_().tamgcn_ctrgc_tiled_agg_fwd(C.byref(d), _ptr(x3[n0:n1]), _ptr(E[n0:n1]), _ptr(y[n0:n1]), _ptr(pc), _stream()),
+                       'tamgcn_ctrgc_tiled_agg_fwd')
+        if stats and len(chunks) > 1:
+            part = torch.cat(parts, dim=2)
+        return y, part, (x3 if keep_x3 else None)
     x3 = empty(N, S * Cout, T, V, like=x.x1) if keep_x3 else None
     _lib.check(_lib_().tamgcn_ctrgc_fwd(C.byref(d), _ptr(y), _ptr(part), _ptr(x3), _stream()), 'tamgcn_ctrgc_fwd')
     return y, part, x3
@@ -262,8 +329,17 @@ def ctrgc_bwd_dx3(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy, E=None, 
     dyc = dy.c()
     dx3 = empty(N, S * Cout, T, V, like=x.x1)
     db3_part = empty(N, S * Cout, like=x.x1)
-    _lib.check(_lib_().tamgcn_ctrgc_bwd_dx3(C.byref(d), C.byref(dyc), _ptr(dx3), _ptr(db3_part), _stream()),
-               'tamgcn_ctrgc_bwd_dx3')
+    if ctrgc_tiled(V):
+        if E is None:
+            E = ctrgc_build_E(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R)
+        for n0, n1 in n_chunks(N, S * Cout * T * V):
+            d.N = n1 - n0
+            dyc = _slice_src(dy, n0, n1).c()
+            _lib.check(_lib_().tamgcn_ctrgc_tiled_agg_bwd(C.byref(d), C.byref(dyc), _ptr(E[n0:n1]), _ptr(dx3[n0:n1]), _ptr(db3_part[n0:n1]),
+                                                          _stream()), 'tamgcn_ctrgc_tiled_agg_bwd')
+    else:
+        _lib.check(_lib_().tamgcn_ctrgc_bwd_dx3(C.byref(d), C.byref(dyc), _ptr(dx3), _ptr(db3_part), _stream()),
+                   'tamgcn_ctrgc_bwd_dx3')
     return dx3, (reduce_sum(db3_part, N, chunks=[(Cout,)] * S) if per_subset else reduce_sum(db3_part, N))
 
 
@@ -276,6 +352,28 @@ def ctrgc_bwd_de(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy, x3=None, 
     d = _ctrgc_desc(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R)
     dyc = dy.c()
     like = x.x1
+    if ctrgc_tiled(V):
+        if x3 is None:
+            x3 = _x3_gemm(x, w3, b3, Cin, Cout, S)
+        NUC = _lib_().tamgcn_ctrgc_tiled_chunks(V)
+        dE = empty(N, S, Cout, V, V, like=like)
+        for n0, n1 in n_chunks(N, S * Cout * T * V):
+            d.N = n1 - n0
+            dyc = _slice_src(dy, n0, n1).c()
+            _lib.check(_lib_().tamgcn_ctrgc_tiled_de_acc(C.byref(d), C.byref(dyc), _ptr(x3[n0:n1]), _ptr(dE[n0:n1]), _stream()),
+                       'tamgcn_ctrgc_tiled_de_acc')
+        d.N = N
+        dA_part = empty(N, S, V, V, like=like)
+        dw4_part = empty(N * NUC, S, Cout, R, like=like)
+        db4_part = empty(N * NUC, S, Cout, like=like)
+        dal_part = empty(N * S * NUC, 1, like=like)
+        dpq = empty(NUC, S * 2 * R, N, V, like=like)
+        _lib.check(_lib_().tamgcn_ctrgc_tiled_de_tail(C.byref(d), _ptr(dE), _ptr(dA_part), _ptr(dw4_part), _ptr(db4_part), _ptr(dal_part),
+                                                      _ptr(dpq), _stream()), 'tamgcn_ctrgc_tiled_de_tail')
+        ps = per_subset
+        return (reduce_sum(dA_part, N), reduce_sum(dw4_part, N * NUC, chunks=[(Cout, R, 1, 1)] * S if ps else None),
+                reduce_sum(db4_part, N * NUC, chunks=[(Cout,)] * S if ps else None), reduce_sum(dal_part, N * S * NUC),
+                reduce_sum(dpq, NUC, immediate=True))
     if x3 is not None and R <= 32:
         dE = empty(N, S, Cout, V, V, like=like)
         _lib.check(_lib_().tamgcn_ctrgc_bwd_de_acc(C.byref(d), C.byref(dyc), _ptr(x3), _ptr(dE), _stream()),

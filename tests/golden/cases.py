@@ -33,6 +33,20 @@ MODULE_CASES = [
     ('unit_64_64',          'TCN_GCN_unit', dict(in_channels=64, out_channels=64, stride=1, residual=True),  (2, 64, 13, 20), 16),
     ('unit_64_128_s2',      'TCN_GCN_unit', dict(in_channels=64, out_channels=128, stride=2, residual=True), (2, 64, 13, 20), 16),
     ('unit_64_128_s2_v25',  'TCN_GCN_unit', dict(in_channels=64, out_channels=128, stride=2, residual=True), (2, 64, 10, 25), 16),
+    # round 2: the wide layers (l8-l10: C = 256, 128 -> 256 stride 2), where the 128-row split data-gradient kernel and
+    # the 4096-workgroup CTRGC grids run
+    ('gcn_256_256',         'unit_gcn',     dict(in_channels=256, out_channels=256),                           (2, 256, 16, 20), 12),
+    ('unit_128_256_s2',     'TCN_GCN_unit', dict(in_channels=128, out_channels=256, stride=2, residual=True),  (2, 128, 32, 20), 16),
+    ('unit_256_256_t16',    'TCN_GCN_unit', dict(in_channels=256, out_channels=256, stride=1, residual=True),  (2, 256, 16, 20), 16),
+    ('unit_256_256_t32',    'TCN_GCN_unit', dict(in_channels=256, out_channels=256, stride=1, residual=True),  (2, 256, 32, 20), 16),
+    ('unit_128_128_v25_t12', 'TCN_GCN_unit', dict(in_channels=128, out_channels=128, stride=1, residual=True), (2, 128, 12, 25), 16),
+    # round 2: V = 64 (BASELINE.json configs[4]); the graph is the build-supplied 64-node tree (graph.synthetic) pushed
+    # through the REFERENCE's graph.tools.get_spatial_graph, the modules are the reference's own classes
+    ('ctrgc_64_64_v64',     'CTRGC',        dict(in_channels=64, out_channels=64),                             (2, 64, 6, 64),  11),
+    ('gcn_64_64_v64',       'unit_gcn',     dict(in_channels=64, out_channels=64),                             (2, 64, 6, 64),  12),
+    ('gcn_128_256_v64',     'unit_gcn',     dict(in_channels=128, out_channels=256),                           (1, 128, 5, 64), 12),
+    ('unit_64_64_v64',      'TCN_GCN_unit', dict(in_channels=64, out_channels=64, stride=1, residual=True),    (2, 64, 9, 64),  16),
+    ('unit_256_256_v64',    'TCN_GCN_unit', dict(in_channels=256, out_channels=256, stride=1, residual=True),  (1, 256, 12, 64), 16),
 ]
 
 NEEDS_A = ('unit_gcn', 'TCN_GCN_unit')      # ctor takes the (3,V,V) graph array
@@ -56,3 +70,6 @@ MODEL_INIT_SEED = 1234
 
 def tag_seed(tag):
     return sum(map(ord, tag))
+
+# harness SGD-step fixtures: name -> (lr, batch, frames)
+SGD_CASES = {'sgd3': (0.05, 4, 13), 'sgd3s': (0.01, 4, 13), 'sgd3b': (0.01, 64, 32)}

@@ -11,11 +11,11 @@ sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
 from cases import MODULE_CASES, NEEDS_A, COT_SEED, tag_seed          # noqa: E402
 from params import fill_state_, make_input, make_labels, digest      # noqa: E402
 
-from tam_gcn_amd.graph import ucla, ntu_rgb_d                        # noqa: E402
+from tam_gcn_amd.graph import ucla, ntu_rgb_d, synthetic             # noqa: E402
 from tam_gcn_amd.models import ctrgcn as M                           # noqa: E402
 from oracle import ctrgcn_oracle as O                                # noqa: E402
 
-A_BY_V = {20: ucla.Graph().A, 25: ntu_rgb_d.Graph().A}
+A_BY_V = {20: ucla.Graph().A, 25: ntu_rgb_d.Graph().A, 64: synthetic.Graph().A}
 
 
 def build_module(kind, kw, V):

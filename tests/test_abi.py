@@ -36,7 +36,8 @@ def test_version_and_error_text_callable_without_gpu():
     assert lib.tamgcn_ctrgc_lds_bytes(3, 20, 8) > 0
     assert lib.tamgcn_ctrgc_lds_bytes(3, 20, 8) <= 160 * 1024
     assert lib.tamgcn_ctrgc_lds_bytes(3, 25, 32) > 0
-    assert lib.tamgcn_ctrgc_lds_bytes(3, 64, 32) < 0        # V=64 tile not built yet: rejected, not mis-run
+    assert 0 < lib.tamgcn_ctrgc_lds_bytes(3, 64, 32) <= 160 * 1024     # V = 64: the tiled family (x3 GEMM + MFMA aggregation)
+    assert lib.tamgcn_ctrgc_lds_bytes(3, 48, 32) < 0        # no tiling for this V: rejected, not mis-run
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
@@ -64,7 +65,9 @@ def test_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert lib.tamgcn_conv_nparts(None) == -1 and lib.tamgcn_wgrad_max_split(None) == -1
     assert lib.tamgcn_ctrgc_lds_bytes(3, 20, 8) > 64 * 1024          # N-UCLA tiles: LDS resident
     assert lib.tamgcn_ctrgc_lds_bytes(3, 25, 8) > 0                  # NTU
-    assert lib.tamgcn_ctrgc_lds_bytes(3, 64, 32) == -1               # V = 64: no LDS-resident tiling (known gap)
+    assert lib.tamgcn_ctrgc_lds_bytes(3, 64, 32) > 0                 # V = 64: tiled family
+    assert lib.tamgcn_ctrgc_tiled_supported(64) == 1 and lib.tamgcn_ctrgc_tiled_supported(20) == 0
+    assert lib.tamgcn_ctrgc_lds_bytes(3, 40, 8) == -1                # neither family
     assert lib.tamgcn_ctrgc_lds_bytes(2, 20, 8) == -1                # subsets: 1 or 3
     # a descriptor with impossible sizes is refused with its own message
     d = _lib.ConvDesc()

@@ -152,12 +152,20 @@ def test_ntu_full_length_against_oracle():
     assert float((g - r).norm() / r.norm()) <= 5e-2 and float((g * r).sum() / (g.norm() * r.norm())) >= 0.999
 
 
+@pytest.mark.parametrize('fix', ['sgd3b', 'sgd3s', 'sgd3'], ids=['lr0.01_b64', 'lr0.01_b4', 'lr0.05_b4_diverging'])
 @pytest.mark.parametrize('flat', [False, True], ids=['torch.optim.SGD', 'ParamArena+SGDNesterov'])
-def test_harness_sgd_steps(flat, golden_models):
+def test_harness_sgd_steps(flat, fix, golden_models):
     """SURVEY §8c-ii on the HIP path: three steps of the harness recipe against the losses and final state captured
     from the reference model -- once with the stock optimiser the reference's processor builds (drop-in), once with the
-    flat parameter arena / gradient bucket / SGDNesterov the data-parallel step uses."""
+    flat parameter arena / gradient bucket / SGDNesterov the data-parallel step uses.
+
+    'sgd3b' (lr 0.01, 64 clips x 32 frames): losses and every tensor of the final state (parameters, running
+    statistics) within 1e-3.  The two 4-clip fixtures have 1040 positions per channel: ONE ReLU-mask flip between two
+    fp32 evaluations moves a gradient by ~1e-2 there (tests/test_gpu_blocks.py holds every block to 1e-5 once flips are
+    excluded), so they keep sanity bars: 2e-2 at lr 0.01, and the diverging lr 0.05 (loss 4.9 -> 6.8 -> 19.7) 10 %."""
+    from cases import SGD_CASES
     from tam_gcn_amd.distributed import ParamArena, SGDNesterov
+    lr, nb, nt = SGD_CASES[fix]
     dev = torch.device('cuda:0')
     m = M.Model(**MODEL_CASES[0][1])
     fill_state_(m.state_dict(), seed=43)
@@ -165,13 +173,13 @@ def test_harness_sgd_steps(flat, golden_models):
     if flat:
         arena = ParamArena(m)
         bucket = arena.grad_bucket()
-        opt = SGDNesterov(arena.params, lr=0.05, momentum=0.9, weight_decay=1e-4, arena=arena, bucket=bucket)
+        opt = SGDNesterov(arena.params, lr=lr, momentum=0.9, weight_decay=1e-4, arena=arena, bucket=bucket)
     else:
-        opt = torch.optim.SGD(m.parameters(), lr=0.05, momentum=0.9, nesterov=True, weight_decay=1e-4)
+        opt = torch.optim.SGD(m.parameters(), lr=lr, momentum=0.9, nesterov=True, weight_decay=1e-4)
     losses = []
     for step in range(3):
-        x = make_input((4, 3, 13, 20, 1), seed=100 + step).to(dev)
-        lab = make_labels(4, 10, seed=200 + step).to(dev)
+        x = make_input((nb, 3, nt, 20, 1), seed=100 + step).to(dev)
+        lab = make_labels(nb, 10, seed=200 + step).to(dev)
         if flat:
             bucket.zero()
         else:
@@ -182,18 +190,27 @@ def test_harness_sgd_steps(flat, golden_models):
             bucket.pack()
         opt.step()
         losses.append(float(loss.detach()))
-    ref = golden_models['sgd3/losses']
-    # the recipe diverges on these random weights (loss 4.9 -> 6.8 -> 19.7): later steps amplify gradient-level differences
-    assert (np.abs(np.array(losses) - ref) <= 5e-3 * np.abs(ref)).all(), (losses, ref)
+    ref, ref64 = golden_models[f'{fix}/losses'], golden_models[f'{fix}/losses64']
+    lbar = {'sgd3b': 1e-3, 'sgd3s': 2e-2, 'sgd3': 5e-3}[fix]
+    ltol = lbar * np.abs(ref64) + NOISE_K * np.abs(ref - ref64)
+    assert (np.abs(np.array(losses) - ref64) <= ltol).all(), (losses, ref, ref64)
     assert abs(losses[0] - ref[0]) <= 1e-4                                       # the first loss is a pure forward
     sd = m.state_dict()
-    assert list(sd.keys()) == [str(k) for k in golden_models['sgd3/keys']]
+    assert list(sd.keys()) == [str(k) for k in golden_models[f'{fix}/keys']]
     got = np.stack([digest(v) for v in sd.values()])
-    refd = golden_models['sgd3/state_digest']
-    # three unstable steps at lr 0.05 amplify the ~1 % flip-level gradient differences of the small pooled-branch biases to
-    # several per cent of the state (the oracle, bit-compatible arithmetic, holds 2e-4: tests/test_model_cpu.py): sanity bar
-    bad = np.abs(got[:, 1] - refd[:, 1]) > 0.1 * np.abs(refd[:, 1]) + 1e-2
-    assert not bad.any(), [(k, got[i, 1], refd[i, 1]) for i, k in enumerate(sd.keys()) if bad[i]][:5]
+    refd, refd64 = golden_models[f'{fix}/state_digest'], golden_models[f'{fix}/state_digest64']
+    noise = np.abs(refd[:, 1] - refd64[:, 1])           # the reference's own fp32-vs-fp64 difference of every state tensor
+    if fix == 'sgd3b':
+        # sum |.| of every state tensor within 1e-3 of the fp64 reference, plus NOISE_K x the reference's own fp32 noise on
+        # that tensor (cancelling-sum gradients: conv1/conv2 biases, alpha) and an absolute floor for few-element tensors
+        bad = np.abs(got[:, 1] - refd64[:, 1]) > 1e-3 * np.abs(refd64[:, 1]) + NOISE_K * noise + 2e-4
+    elif fix == 'sgd3s':
+        bad = np.abs(got[:, 1] - refd64[:, 1]) > 2e-2 * np.abs(refd64[:, 1]) + NOISE_K * noise + 2e-3
+    else:
+        # three unstable steps at lr 0.05 amplify flip-level gradient differences of the small pooled-branch biases to
+        # several per cent of the state (the oracle, bit-compatible arithmetic, holds 2e-4: tests/test_model_cpu.py)
+        bad = np.abs(got[:, 1] - refd[:, 1]) > 0.1 * np.abs(refd[:, 1]) + 1e-2
+    assert not bad.any(), [(k, got[i, 1], refd[i, 1], refd64[i, 1]) for i, k in enumerate(sd.keys()) if bad[i]][:5]
 
 
 def test_frozen_backbone_usage():

@@ -86,3 +86,30 @@ def test_module_parity(case, golden_modules):
     with torch.no_grad():
         ye = mod(x.detach(), A.detach(), alpha.detach()) if kind == 'CTRGC' else mod(x.detach())
     _cmp_gold('y_eval vs golden', ye, gold, f'{tag}/y_eval', REL_Y * 2)
+
+
+def test_large_tensor_chunking_matches_single_launch(monkeypatch):
+    """The V = 64, T = 512, C = 256 configuration at 256 clips has tensors of more than 2^31 elements (x3: 6.4e9); ops
+    then split the launches over clips.  Forced here at a small size (one clip per launch): forward and every gradient
+    equal the single-launch results to rounding."""
+    from tam_gcn_amd import ops
+    tag, kind, kw, shape, xseed = next(c for c in MODULE_CASES if c[0] == 'unit_64_64_v64')
+    dev = torch.device('cuda:0')
+
+    def run():
+        mod = build_module(kind, kw, shape[-1])
+        fill_state_(mod.state_dict(), seed=tag_seed(tag))
+        mod = mod.to(dev).train()
+        x = make_input(shape, xseed).to(dev).requires_grad_(True)
+        y = mod(x)
+        (y * make_input(tuple(y.shape), COT_SEED).to(dev)).sum().backward()
+        torch.cuda.synchronize()
+        return y.detach(), x.grad, {k: p.grad for k, p in mod.named_parameters()}
+
+    y0, dx0, g0 = run()
+    monkeypatch.setattr(ops, 'CHUNK_ELEMS', shape[1] * shape[2] * shape[3])      # < the 3-subset x3 of one clip: 1 clip / launch
+    y1, dx1, g1 = run()
+    _cmp('y', y1, y0.cpu(), 1e-6)
+    _cmp('dx', dx1, dx0.cpu(), 1e-5)
+    for k in g0:
+        _cmp(k, g1[k], g0[k].cpu(), 2e-5, 1e-7)

@@ -30,6 +30,14 @@ def test_synthetic_graph_recipe():
     assert np.allclose(col[col > 0], 1.0)            # column-normalised
 
 
+def test_synthetic_graph_equals_reference_recipe():
+    """The build's 64-node tree through OUR get_spatial_graph == the same parent table through the reference's
+    graph.tools.get_spatial_graph (fixture written by tests/golden/make_golden.py)."""
+    import os
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'graphs.npz'))
+    assert np.array_equal(synthetic.Graph().A, gold['syn64'])
+
+
 def test_bad_labeling_mode_raises():
     import pytest
     with pytest.raises(ValueError):

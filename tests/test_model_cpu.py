@@ -109,27 +109,30 @@ def test_oracle_model_vs_golden(case, golden_models):
         np.testing.assert_allclose(l3.numpy(), gold[f'{tag}/logits_eval_3d'], rtol=1e-3, atol=1e-3)
 
 
-def test_harness_sgd_steps_oracle(golden_models):
+@pytest.mark.parametrize('fix', ['sgd3', 'sgd3s', 'sgd3b'])
+def test_harness_sgd_steps_oracle(fix, golden_models):
     """three steps of the harness recipe (SGD momentum 0.9, nesterov, wd 1e-4 + CE, reference
     processor/recognition_rgb.py:19-28) captured from the reference model: the oracle under torch.optim.SGD reproduces
     the losses and the final state (parameters, running statistics, num_batches_tracked)."""
+    from cases import SGD_CASES
+    lr, nb, nt = SGD_CASES[fix]
     margs = MODEL_CASES[0][1]
     m = M.Model(**margs)
     fill_state_(m.state_dict(), seed=43)
     sd = O.clone_state(m.state_dict(), requires_grad=True)
     params = [v for v in sd.values() if v.requires_grad]
-    opt = torch.optim.SGD(params, lr=0.05, momentum=0.9, nesterov=True, weight_decay=1e-4)
+    opt = torch.optim.SGD(params, lr=lr, momentum=0.9, nesterov=True, weight_decay=1e-4)
     losses = []
     for step in range(3):
-        x = make_input((4, 3, 13, 20, 1), seed=100 + step)
-        lab = make_labels(4, 10, seed=200 + step)
+        x = make_input((nb, 3, nt, 20, 1), seed=100 + step)
+        lab = make_labels(nb, 10, seed=200 + step)
         opt.zero_grad()
         loss = torch.nn.functional.cross_entropy(O.model_forward(x, sd, 20, training=True), lab)
         loss.backward()
         opt.step()
         losses.append(float(loss.detach()))
-    np.testing.assert_allclose(losses, golden_models['sgd3/losses'], rtol=2e-5, atol=2e-6)
-    assert list(sd.keys()) == [str(k) for k in golden_models['sgd3/keys']]
+    np.testing.assert_allclose(losses, golden_models[f'{fix}/losses'], rtol=2e-5, atol=2e-6)
+    assert list(sd.keys()) == [str(k) for k in golden_models[f'{fix}/keys']]
     got = np.stack([digest(v) for v in sd.values()])
-    ref = golden_models['sgd3/state_digest']
+    ref = golden_models[f'{fix}/state_digest']
     np.testing.assert_allclose(got[:, 1], ref[:, 1], rtol=2e-4, atol=1e-5)        # sum |.| of every state tensor
