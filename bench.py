@@ -95,7 +95,7 @@ def _src_reads(s):
 
 def _layer_tag(name, args):
     """'Cin->Cout,T' of a fused-CTRGC forward launch (the per-layer roofline table), else None."""
-    if name != 'tamgcn_ctrgc_fwd':
+    if name not in ('tamgcn_ctrgc_fwd', 'tamgcn_ctrgc_tiled_agg_fwd'):
         return None
     d = args[0]._obj
     return f'{d.Cin}->{d.Cout},T{d.T},V{d.V}'
@@ -120,6 +120,15 @@ def _algorithmic(name, args):
         b = d.N * d.T * d.V * (d.Cin + d.Cout)
         f = d.N * d.S * (2.0 * d.Cin * d.Cout * d.T * d.V + 2.0 * d.R * d.Cout * d.V * d.V + 2.0 * d.Cout * d.T * d.V * d.V)
         return (4.0 * b, f)
+    if name == 'tamgcn_ctrgc_tiled_agg_fwd':       # x3 (S*Cout) in, y out, E once; the dense W3.x GEMM is a tamgcn_conv launch of its own
+        b = d.N * d.T * d.V * (d.S * d.Cout + d.Cout) + d.N * d.S * d.Cout * d.V * d.V
+        return (4.0 * b, 2.0 * d.N * d.S * d.Cout * d.T * d.V * d.V)
+    if name == 'tamgcn_ctrgc_tiled_agg_bwd':
+        b = d.N * d.T * d.V * (d.S * d.Cout + 2 * d.Cout) + d.N * d.S * d.Cout * d.V * d.V
+        return (4.0 * b, 2.0 * d.N * d.S * d.Cout * d.T * d.V * d.V)
+    if name == 'tamgcn_ctrgc_tiled_de_acc':
+        b = d.N * d.T * d.V * (d.S * d.Cout + 2 * d.Cout) + d.N * d.S * d.Cout * d.V * d.V
+        return (4.0 * b, 2.0 * d.N * d.S * d.Cout * d.T * d.V * d.V)
     if name == 'tamgcn_ctrgc_bwd_dx3':
         b = d.N * d.T * d.V * (2 * d.Cout + d.S * d.Cout)
         f = d.N * d.S * (2.0 * d.R * d.Cout * d.V * d.V + 2.0 * d.Cout * d.T * d.V * d.V)

@@ -107,7 +107,8 @@ def test_large_tensor_chunking_matches_single_launch(monkeypatch):
         return y.detach(), x.grad, {k: p.grad for k, p in mod.named_parameters()}
 
     y0, dx0, g0 = run()
-    monkeypatch.setattr(ops, 'CHUNK_ELEMS', shape[1] * shape[2] * shape[3])      # < the 3-subset x3 of one clip: 1 clip / launch
+    # two clips of one activation fit, the 3-subset x3 / dx3 (6 activations' worth) do not: those go one clip per launch
+    monkeypatch.setattr(ops, 'CHUNK_ELEMS', 2 * shape[1] * shape[2] * shape[3])
     y1, dx1, g1 = run()
     _cmp('y', y1, y0.cpu(), 1e-6)
     _cmp('dx', dx1, dx0.cpu(), 1e-5)
