@@ -313,6 +313,13 @@ int tamgcn_head_fc_fwd(const float* pooled, const float* W, const float* b, int 
 int tamgcn_head_fc_bwd(const float* dlogits, const float* pooled, const float* W, int N, int C, int K,
                        float* dW, float* db, float* dpooled, void* stream);
 
+/* ---- loss of the harness step (nn.CrossEntropyLoss(), reduction 'mean': reference processor/recognition_rgb.py:19, :62) ----
+ * _ce_fwd  loss[0] = mean_n (logsumexp(logits[n]) - logits[n][labels[n]]); g (N, K) = softmax - onehot (kept for the backward);
+ *          labels int64 on the device, every label in [0, K).  One launch (aten: log_softmax + nll_loss).
+ * _ce_bwd  dlogits = g * dloss[0] / N   (aten: nll_loss_backward + log_softmax_backward). */
+int tamgcn_ce_fwd(const float* logits, const long long* labels, int N, int K, float* loss, float* g, void* stream);
+int tamgcn_ce_bwd(const float* g, const float* dloss, int N, int K, float* dlogits, void* stream);
+
 /* ---- input side: skeleton streams and the feeder's per-sample transform ----------------------
  * _stream_derive  the other three inputs of the 4-stream recipe from a joint batch x (N, C, T, V, M) resident in HBM:
  *                 mode 1 bone        out[.., v, m] = x[.., v, m] - x[.., parent[v], m]   (reference feeder/feeder_nucla_gcn.py:27-28,

@@ -111,6 +111,38 @@ __global__ __launch_bounds__(SH_NT) void fc_bwd_kernel(const float* dl, const fl
     }
 }
 
+// ---- cross-entropy over the logits (nn.CrossEntropyLoss, reduction 'mean': reference processor/recognition_rgb.py:19, :62) ----
+// ONE workgroup: thread -> samples n = tid, tid + 256, ...; per sample lse by max-shift, the loss term, and
+// g[n][k] = softmax_k - [k == y_n] (the backward only scales it).  Terms are summed in fp64 in a fixed order.
+__global__ __launch_bounds__(SH_NT) void ce_fwd_kernel(const float* logits, const long long* labels, int N, int K, float* loss, float* g) {
+    __shared__ double red[SH_NT];
+    double acc = 0.0;
+    for (int n = threadIdx.x; n < N; n += SH_NT) {
+        const float* l = logits + (long long)n * K;
+        float m = l[0];
+        for (int k = 1; k < K; ++k) m = fmaxf(m, l[k]);
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s += expf(l[k] - m);
+        const float lse = m + logf(s);
+        const long long y = labels[n];
+        const float inv = 1.f / s;
+        for (int k = 0; k < K; ++k) g[(long long)n * K + k] = expf(l[k] - m) * inv - (k == y ? 1.f : 0.f);
+        acc += (double)(lse - l[y]);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = SH_NT / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = (float)(red[0] / (double)N);
+}
+
+__global__ __launch_bounds__(SH_NT) void ce_bwd_kernel(const float* g, const float* dloss, int total, float scale, float* dlogits) {
+    const int e = blockIdx.x * SH_NT + threadIdx.x;
+    if (e < total) dlogits[e] = g[e] * (dloss[0] * scale);
+}
+
 }  // namespace
 
 static bool sh_dims_ok(int N, int C, int T, int V, int M) {
@@ -169,5 +201,22 @@ extern "C" int tamgcn_head_fc_bwd(const float* dlogits, const float* pooled, con
     hipLaunchKernelGGL(fc_bwd_kernel, dim3(K + N), dim3(SH_NT), 0, (hipStream_t)stream, dlogits, pooled, W, N, C, K, dW, db, dpooled);
     tamgcn_note_kernel("fc_bwd_kernel");
     TG_LAUNCH_CHECK("tamgcn_head_fc_bwd");
+    return 0;
+}
+
+extern "C" int tamgcn_ce_fwd(const float* logits, const long long* labels, int N, int K, float* loss, float* g, void* stream) {
+    TG_CHECK(logits && labels && loss && g && N > 0 && K > 0, "tamgcn_ce_fwd: bad args");
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(1), dim3(SH_NT), 0, (hipStream_t)stream, logits, labels, N, K, loss, g);
+    tamgcn_note_kernel("ce_fwd_kernel");
+    TG_LAUNCH_CHECK("tamgcn_ce_fwd");
+    return 0;
+}
+
+extern "C" int tamgcn_ce_bwd(const float* g, const float* dloss, int N, int K, float* dlogits, void* stream) {
+    TG_CHECK(g && dloss && dlogits && N > 0 && K > 0, "tamgcn_ce_bwd: bad args");
+    const int total = N * K;
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)ceil_div(total, SH_NT)), dim3(SH_NT), 0, (hipStream_t)stream, g, dloss, total, 1.f / (float)N, dlogits);
+    tamgcn_note_kernel("ce_bwd_kernel");
+    TG_LAUNCH_CHECK("tamgcn_ce_bwd");
     return 0;
 }

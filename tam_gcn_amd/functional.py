@@ -627,3 +627,167 @@ class HeadFn(torch.autograd.Function):
         dW, db, dpooled = ops.head_fc_bwd(dl.contiguous(), pooled, W)
         dx = ops.head_pool_bwd(dpooled, ctx.M, *ctx.TV) if ctx.needs_input_grad[0] else None
         return dx, dW, db, None
+
+
+# ===========================================================================
+# loss of the harness step -- SURVEY.md §8 row f1 (reference processor/recognition_rgb.py:19, :62: nn.CrossEntropyLoss())
+# ===========================================================================
+class CrossEntropyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels):
+        logits = logits.contiguous()
+        loss, g = ops.ce_fwd(logits, labels.contiguous())
+        ctx.save_for_backward(g)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (g,) = ctx.saved_tensors
+        return ops.ce_bwd(g, dloss.to(torch.float32).contiguous()), None
+
+
+class CrossEntropyLoss(torch.nn.Module):
+    """Drop-in for the ``nn.CrossEntropyLoss()`` the reference's processors build (default arguments: mean reduction, no
+    class weights, no label smoothing, no ignore_index hits): two HIP launches instead of four aten kernels."""
+
+    def forward(self, logits, labels):
+        if logits.dim() != 2 or labels.dim() != 1 or labels.dtype != torch.int64 or logits.dtype != torch.float32:
+            raise RuntimeError('tam_gcn_amd.CrossEntropyLoss: expected (N, K) fp32 logits and (N,) int64 class indices')
+        if not logits.is_cuda:
+            raise RuntimeError('tam_gcn_amd: the loss runs on MI355X only (got a CPU tensor); there is no CPU fallback')
+        return CrossEntropyFn.apply(logits, labels)
+
+
+# ===========================================================================
+# ST-GCN block (reference models/stgcn.py:37-99) -- SURVEY.md §8 row f4.
+# The spatial graph convolution  einsum('nkctv,kvw->nctw')  of conv(x) with the static A * edge_importance is CTRGC's
+# aggregation with a topology that does not depend on the sample or the channel: E_k[n,c,u,v] = (A*imp)[k,v,u], i.e. the
+# fused CTRGC kernels with alpha = 0 (E = alpha*(W4 tanh(.) + b4) + A = A).  conv3 plays the 1x1 conv (Cin -> K*Cout).
+# ===========================================================================
+def _stgcn_ctrgc_args(x, Ae, W3, B3, Cout):
+    K, V = Ae.shape[0], Ae.shape[1]
+    N = x.shape[0]
+    dev = x.device
+    R = 4                                               # smallest rel-channel count the kernels take; all-zero refinement
+    z = torch.zeros
+    return dict(pq=z(K * 2 * R, N, V, device=dev), w4=z(K, Cout, R, device=dev), b4=z(K, Cout, device=dev),
+                A=Ae.transpose(1, 2).contiguous(), alpha=z(1, device=dev), R=R, K=K)
+
+
+class StGcnFn(torch.autograd.Function):
+    """relu(tcn(gcn(x, A)) + residual(x)) of one st_gcn block as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, mod, x, Ae, w3, b3, g1, be1, wt, bt, g2, be2, *res_params):
+        N, Cin, T, V = x.shape
+        Cout, s, kt = mod.out_channels, mod.stride, mod.t_kernel
+        training = mod.training
+        save = _needs(ctx)
+        bn1, bn2 = BN(mod.tcn[0]), BN(mod.tcn[3])
+        xs = S(x)
+        W3, Ae = w3.reshape(w3.shape[0], Cin), Ae.contiguous()
+        a = _stgcn_ctrgc_args(x, Ae, W3, b3, Cout)
+        cargs = (xs, a['pq'], W3, b3, a['w4'], a['b4'], a['A'], a['alpha'], Cin, Cout, a['K'], a['R'])
+        y_pre, ypart, x3 = ops.ctrgc_fwd(*cargs, stats=training, keep_x3=save and KEEP_X3)
+        cnt1 = N * T * V
+        coef1, save1 = _coef(Cout, x)
+        bn1.fwd(ypart, 0, cnt1, training, coef1, save1, 0)
+        pad = (kt - 1) // 2
+        z_pre, zpart = ops.conv(S(y_pre, coef=coef1, act=RELU), K=Cout, w=wt, bias=bt, M=Cout, KT=kt, stride=s, pad=pad, stats=training)
+        T2 = z_pre.shape[2]
+        cnt2 = N * T2 * V
+        coef2, save2 = _coef(Cout, x)
+        bn2.fwd(zpart, 0, cnt2, training, coef2, save2, 0)
+        r_pre = coef_r = save_r = None
+        if mod._rmode == 'identity':
+            res = xs
+        elif mod._rmode == 'conv':
+            wr, br = res_params[0], res_params[1]
+            bnr = BN(mod.residual[1])
+            r_pre, rpart = ops.conv(xs, K=Cin, w=wr, bias=br, M=Cout, KT=1, stride=s, pad=0, T_out=T2, stats=training)
+            coef_r, save_r = _coef(Cout, x)
+            bnr.fwd(rpart, 0, cnt2, training, coef_r, save_r, 0)
+            res = S(r_pre, coef=coef_r)
+        else:
+            res = None
+        out = ops.add_act_fwd(S(z_pre, coef=coef2), res, True, Cout)
+        if save:
+            ctx.sv = dict(x=x, Ae=Ae, W3=W3, b3=b3, a=a, x3=x3, y_pre=y_pre, z_pre=z_pre, r_pre=r_pre, out=out, coef1=coef1, save1=save1,
+                          coef2=coef2, save2=save2, coef_r=coef_r, save_r=save_r, wt=wt, res_params=res_params, training=training)
+        ctx.mod = mod
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        mod, sv = ctx.mod, ctx.sv
+        ctx.sv = None
+        x, W3, b3, a = sv['x'], sv['W3'], sv['b3'], sv['a']
+        y_pre, z_pre, r_pre, out, wt = sv['y_pre'], sv['z_pre'], sv['r_pre'], sv['out'], sv['wt']
+        training = sv['training']
+        N, Cin, T, V = x.shape
+        Cout, s, kt = mod.out_channels, mod.stride, mod.t_kernel
+        T2 = z_pre.shape[2]
+        cnt1, cnt2 = N * T * V, N * T2 * V
+        pad = (kt - 1) // 2
+        need_dx = ctx.needs_input_grad[1]
+        bn1, bn2 = BN(mod.tcn[0]), BN(mod.tcn[3])
+        xs = S(x)
+        with ops.ReduceBatch():
+            dz, part = ops.add_act_bwd(dout.contiguous(), out, 1, z_pre, sv['save2'], r_pre, sv['save_r'], want_dz=True)
+            coefb2 = torch.empty(3, Cout, device=x.device)
+            dg2, dbe2, dbt = bn2.bwd(part, 0, cnt2, sv['save2'], 0, training, coefb2, 0, want_dbias=True)
+            gz = S(dz, z_pre, coefb2)
+            h = S(y_pre, coef=sv['coef1'], act=RELU)
+            dwt = ops.wgrad(gz, h, M=Cout, K=Cout, KT=kt, stride=s, pad=pad)
+            dh, hp = ops.conv(gz, K=Cout, w=wt, bias=None, M=Cout, KT=kt, dil=1, stride=1, pad=(kt - 1) - pad, wmode=1, up=s, T_out=T,
+                              mask=S(y_pre, coef=sv['coef1']), aux=y_pre, aux_center=sv['save1'], auxcoff=0, stats=True)
+            coefb1 = torch.empty(3, Cout, device=x.device)
+            dg1, dbe1, _ = bn1.bwd(hp, 0, cnt1, sv['save1'], 0, training, coefb1, 0)
+            dy = S(dh, y_pre, coefb1)
+            cargs = (xs, a['pq'], W3, b3, a['w4'], a['b4'], a['A'], a['alpha'], Cin, Cout, a['K'], a['R'], dy)
+            dx3, db3 = ops.ctrgc_bwd_dx3(*cargs)
+            dA, _, _, _, _ = ops.ctrgc_bwd_de(*cargs, x3=sv['x3'])
+            dw3 = ops.wgrad(S(dx3), xs, M=a['K'] * Cout, K=Cin)
+            gres = []
+            add1 = None
+            if mod._rmode == 'identity':
+                add1 = dz
+            elif mod._rmode == 'conv':
+                wr = sv['res_params'][0]
+                bnr = BN(mod.residual[1])
+                coefb_r = torch.empty(3, Cout, device=x.device)
+                dgr, dber, dbr = bnr.bwd(part[2:4], 0, cnt2, sv['save_r'], 0, training, coefb_r, 0, True)
+                gyr = S(dz, r_pre, coefb_r)
+                dwr = ops.wgrad(gyr, xs, M=Cout, K=Cin, KT=1, stride=s, pad=0)
+                gres = [dwr, dbr, dgr, dber]
+                if need_dx:
+                    add1 = torch.zeros_like(x) if s > 1 else torch.empty_like(x)
+                    ops.conv(gyr, K=Cout, w=wr, bias=None, M=Cin, wmode=1, y=add1, T_out=T2, ostride=s)
+            dx = None
+            if need_dx:
+                dx, _ = ops.conv(S(dx3), K=a['K'] * Cout, w=W3, bias=None, M=Cin, wmode=1, add1=add1)
+        dAe = dA.transpose(1, 2) if ctx.needs_input_grad[2] else None
+        return (None, dx, dAe, dw3.reshape(a['K'] * Cout, Cin, 1, 1), db3, dg1, dbe1, dwt, dbt, dg2, dbe2, *gres)
+
+
+class PointwiseConvFn(torch.autograd.Function):
+    """1x1 convolution with bias over (N, C, T, V) (ST-GCN's `fcn` applied per position in extract_feature, stgcn.py:218-219)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = x.contiguous()
+        y, _ = ops.conv(S(x), K=x.shape[1], w=w.reshape(w.shape[0], -1), bias=b, M=w.shape[0])
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        M, K = w.shape[0], x.shape[1]
+        dw = ops.wgrad(S(dy), S(x), M=M, K=K).reshape(w.shape)
+        db = dy.sum((0, 2, 3))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx, _ = ops.conv(S(dy), K=M, w=w.reshape(M, K), bias=None, M=K, wmode=1)
+        return dx, dw, db

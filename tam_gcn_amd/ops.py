@@ -50,7 +50,7 @@ def _lib_():
 # Kernels index one launch's tensors with 32-bit element offsets inside a sample block and refuse tensors of >= 2^32
 # elements; the V = 64, T = 512, C = 256 configuration at 256 clips has a 6.4e9-element x3.  Such calls are split over
 # the clip dimension N (clips are independent; every tensor is contiguous in n) into launches below this bound.
-CHUNK_ELEMS = int(os.environ.get('TAMGCN_CHUNK_ELEMS', str(2 ** 31 - 1)))
+CHUNK_ELEMS = int(os.environ.get("TAMGCN_CHUNK_ELEMS", str(2 ** 32 - 1)))
 
 
 def n_chunks(N, per_clip):
@@ -566,3 +566,20 @@ def feeder_transform(raw, offsets, rot, idx, parent, V, time_steps, center_joint
     _lib.check(_lib_().tamgcn_feeder_transform(_ptr(raw), _ptr(offsets), _ptr(rot), _ptr(idx), _ptr(parent), N, V, time_steps,
                                                center_joint, m, _ptr(out), _stream()), 'tamgcn_feeder_transform')
     return out
+
+
+# ---------------------------------------------------------------------------
+# loss of the harness step
+def ce_fwd(logits, labels):
+    N, K = logits.shape
+    loss = torch.empty((), device=logits.device, dtype=torch.float32)
+    g = torch.empty_like(logits)
+    _lib.check(_lib_().tamgcn_ce_fwd(_ptr(logits), _ptr(labels), N, K, _ptr(loss), _ptr(g), _stream()), 'tamgcn_ce_fwd')
+    return loss, g
+
+
+def ce_bwd(g, dloss):
+    N, K = g.shape
+    dl = torch.empty_like(g)
+    _lib.check(_lib_().tamgcn_ce_bwd(_ptr(g), _ptr(dloss), N, K, _ptr(dl), _stream()), 'tamgcn_ce_bwd')
+    return dl

@@ -73,3 +73,14 @@ def tag_seed(tag):
 
 # harness SGD-step fixtures: name -> (lr, batch, frames)
 SGD_CASES = {'sgd3': (0.05, 4, 13), 'sgd3s': (0.01, 4, 13), 'sgd3b': (0.01, 64, 32)}
+
+# ST-GCN (reference models/stgcn.py): st_gcn blocks with temporal kernel 9, 3 spatial partitions
+STGCN_BLOCK_CASES = [
+    ('stgcn_3_64_nores',  dict(in_channels=3, out_channels=64, stride=1, residual=False),  (2, 3, 13, 20),  41),
+    ('stgcn_64_64',       dict(in_channels=64, out_channels=64, stride=1, residual=True),  (2, 64, 13, 20), 41),
+    ('stgcn_64_128_s2',   dict(in_channels=64, out_channels=128, stride=2, residual=True), (2, 64, 12, 20), 41),
+    ('stgcn_256_256',     dict(in_channels=256, out_channels=256, stride=1, residual=True), (2, 256, 8, 20), 41),
+]
+_STGCN_UCLA = dict(in_channels=3, num_class=4, num_point=20, num_person=1, graph='graph.ucla.Graph',
+                   graph_args=dict(labeling_mode='spatial'))
+STGCN_MODEL_CASES = [('stgcn_ucla_t16', _STGCN_UCLA, (3, 3, 16, 20, 1)), ('stgcn_ucla_t52', _STGCN_UCLA, (2, 3, 52, 20, 1))]

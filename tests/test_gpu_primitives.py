@@ -361,3 +361,20 @@ def test_stem_and_head_against_torch(shape, training):
     (lg * cl.to(d)).sum().backward()
     close(lg, lo, 1e-4, 1e-5, 'logits')
     close(hg.grad, h.grad, 1e-4, 1e-7, 'head dx'); close(Wg.grad, W.grad, 1e-4, 1e-6, 'dW'); close(bg.grad, b.grad, 1e-4, 1e-6, 'db')
+
+
+def test_cross_entropy_against_torch():
+    """tamgcn_ce_fwd / _bwd against torch's CrossEntropyLoss on the same logits: loss and gradient."""
+    from tam_gcn_amd.functional import CrossEntropyLoss
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(5)
+    for N, K in [(256, 10), (7, 60), (1, 3), (1000, 10)]:
+        logits = (torch.randn(N, K, generator=g) * 3).to(dev).requires_grad_(True)
+        lab = torch.randint(0, K, (N,), generator=g).to(dev)
+        loss = CrossEntropyLoss()(logits, lab)
+        (loss * 1.7).backward()
+        ref_l = logits.detach().double().clone().requires_grad_(True)
+        ref = torch.nn.functional.cross_entropy(ref_l, lab)
+        (ref * 1.7).backward()
+        assert abs(float(loss) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+        assert (logits.grad.double() - ref_l.grad).abs().max() <= 2e-7

@@ -1,0 +1,106 @@
+"""-m gpu: the ST-GCN block and model on the HIP path (the spatial graph convolution runs on the fused
+CTRGC kernels with a static topology) against the CPU oracle and the vectors generated from the reference's models/stgcn.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from cases import STGCN_BLOCK_CASES, STGCN_MODEL_CASES, COT_SEED, tag_seed     # noqa: E402
+from params import fill_state_, make_input, make_labels, digest               # noqa: E402
+from oracle import stgcn_oracle as SO                                           # noqa: E402
+from tam_gcn_amd.graph import ucla                                              # noqa: E402
+from tam_gcn_amd.models import stgcn as M                                       # noqa: E402
+from test_stgcn_oracle import GOLD, A, rmode, fill_stgcn_, get                  # noqa: E402
+
+
+def _cmp(name, got, ref, rel, atol=0.0):
+    got, ref = got.detach().cpu().double(), torch.as_tensor(ref).double()
+    assert got.shape == ref.shape, f'{name}: {tuple(got.shape)} vs {tuple(ref.shape)}'
+    scale = float(ref.abs().max()) + 1e-6
+    err = float((got - ref).abs().max())
+    assert err <= rel * scale + atol, f'{name}: max-abs-err {err:.3e} > {rel:g} * {scale:.3e} + {atol:g}'
+
+
+def _cmp_gold(name, got, key, rel, atol=0.0):
+    ref, dig = get(key)
+    if dig:
+        g = digest(got)
+        assert abs(g[1] - ref[1]) <= rel * abs(ref[1]) + 1e-6 * got.numel(), f'{name}: abs-sum {g[1]} vs {ref[1]}'
+    else:
+        _cmp(name, got, ref, rel, atol)
+
+
+@pytest.mark.parametrize('case', STGCN_BLOCK_CASES, ids=[c[0] for c in STGCN_BLOCK_CASES])
+def test_block_parity(case):
+    tag, kw, shape, xseed = case
+    dev = torch.device('cuda:0')
+    blk = M.st_gcn(kw['in_channels'], kw['out_channels'], (9, 3), kw.get('stride', 1), residual=kw.get('residual', True))
+    fill_state_(blk.state_dict(), seed=tag_seed(tag))
+    sd = {'m.' + k: v.detach().clone().requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in blk.state_dict().items()}
+    imp_o = (1 + 0.1 * make_input((3, 20, 20), seed=31)).requires_grad_(True)
+    xo = make_input(shape, xseed).requires_grad_(True)
+    yo = SO.st_gcn(xo, sd, 'm', A * imp_o, kw.get('stride', 1), rmode(kw), True)
+    cot = make_input(tuple(yo.shape), seed=COT_SEED)
+    (yo * cot).sum().backward()
+    blk = blk.to(dev).train()
+    x = make_input(shape, xseed).to(dev).requires_grad_(True)
+    imp = (1 + 0.1 * make_input((3, 20, 20), seed=31)).to(dev).requires_grad_(True)
+    y, A_out = blk(x, A.to(dev) * imp)
+    (y * cot.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    REL_Y, REL_G = 1e-4, 1e-3
+    _cmp('y vs oracle', y, yo.detach(), REL_Y); _cmp_gold('y vs golden', y, f'{tag}/y', 2 * REL_Y)
+    _cmp('dx vs oracle', x.grad, xo.grad, REL_G); _cmp_gold('dx vs golden', x.grad, f'{tag}/dx', 2 * REL_G)
+    _cmp('d importance vs oracle', imp.grad, imp_o.grad, REL_G); _cmp_gold('d importance vs golden', imp.grad, f'{tag}/dimp', 2 * REL_G)
+    for k, p in blk.named_parameters():
+        go = sd['m.' + k].grad
+        if k.endswith('bias') and float(go.abs().max()) < 2e-4:      # bias in front of a train-mode BatchNorm: exactly 0 in exact arithmetic
+            assert float(p.grad.abs().max()) < 2e-3, k
+            continue
+        _cmp(f'grad {k} vs oracle', p.grad, go, REL_G, 2e-5)
+        _cmp_gold(f'grad {k} vs golden', p.grad, f'{tag}/grad/{k}', 2 * REL_G, 2e-5)
+    for k, b in blk.named_buffers():
+        _cmp(f'buffer {k}', b.float(), sd['m.' + k].detach().float(), 1e-4)
+    blk.eval()
+    with torch.no_grad():
+        ye, _ = blk(x.detach(), A.to(dev) * imp.detach())
+    _cmp_gold('y_eval vs golden', ye, f'{tag}/y_eval', 2 * REL_Y)
+
+
+@pytest.mark.parametrize('case', STGCN_MODEL_CASES, ids=[c[0] for c in STGCN_MODEL_CASES])
+def test_model_parity(case):
+    tag, margs, shape = case
+    dev = torch.device('cuda:0')
+    m = M.Model(**margs)
+    fill_stgcn_(m.state_dict(), seed=77)
+    m = m.to(dev).train()
+    x = make_input(shape, seed=21).to(dev).requires_grad_(True)
+    lab = make_labels(shape[0], margs['num_class'], seed=22).to(dev)
+    logits = m(x)
+    loss = torch.nn.functional.cross_entropy(logits, lab)
+    loss.backward()
+    torch.cuda.synchronize()
+    lg, ref = logits.detach().cpu().numpy(), GOLD[f'{tag}/logits_train']
+    assert np.abs(lg - ref).max() <= 1e-3 and np.array_equal(lg.argmax(1), ref.argmax(1))
+    assert abs(float(loss.detach()) - float(GOLD[f'{tag}/loss'])) <= 1e-3
+    for k, p in m.named_parameters():
+        key = f'{tag}/grad/{k}'
+        if key in GOLD.files:                                   # fcn (forward features only: tight) and edge_importance (through the stack: flip-robust)
+            g, r = p.grad.detach().cpu().double().numpy(), GOLD[key].astype(np.float64)
+            l2 = np.sqrt(((g - r) ** 2).sum()) / (np.sqrt((r ** 2).sum()) + 1e-30)
+            assert l2 <= (2e-3 if k.startswith('fcn.') else 5e-2), f'{k}: relative L2 {l2:.3e}'
+    dx, rdx = x.grad.cpu().double().numpy(), GOLD[f'{tag}/dx'].astype(np.float64)
+    assert np.sqrt(((dx - rdx) ** 2).sum()) / np.sqrt((rdx ** 2).sum()) <= 5e-2
+    m.eval()
+    with torch.no_grad():
+        le = m(x.detach()).cpu().numpy()
+        o, f = m.extract_feature(x.detach())
+    assert np.abs(le - GOLD[f'{tag}/logits_eval']).max() <= 1e-3
+    assert list(f.shape) == list(GOLD[f'{tag}/feat_shape']) and list(o.shape) == list(GOLD[f'{tag}/out_shape'])
+    assert abs(digest(f)[1] - GOLD[f'{tag}/feat_digest'][1]) <= 1e-4 * abs(GOLD[f'{tag}/feat_digest'][1])
+    assert abs(digest(o)[1] - GOLD[f'{tag}/out_digest'][1]) <= 1e-3 * abs(GOLD[f'{tag}/out_digest'][1])
+    js = m.get_edge_importance_per_joint()
+    assert js.shape == (20,) and abs(js.max() - 1.0) < 1e-12
