@@ -15,7 +15,10 @@
  *     hipGraph stream capture; scratch/partial buffers are caller-provided;
  *   - return value 0 = launched; <0 = rejected before any launch
  *     (tamgcn_last_error() gives the reason for the calling thread);
- *   - calls are re-entrant per stream: no global mutable state.
+ *   - calls are re-entrant per stream: no global mutable state;
+ *   - skeletons whose joint count V is not a multiple of 4 (NTU: 25): the 16-byte kernels read the last piece of a frame
+ *     whole, i.e. up to 12 bytes past the last element of a SOURCE activation -- such buffers must be readable for 16 bytes
+ *     behind their end (the Python layer allocates that slack and copies caller tensors that lack it).
  *
  * "src" operands.  Most kernels read their activation operand through a fused
  * per-channel affine/mix prologue so that train-mode BatchNorm apply (forward)

@@ -43,8 +43,14 @@ struct ConvArgs {
     int TIN;       // input frame slots staged per block
     int lstride;   // frame step between staged slots (stride for 1x1, else 1)
     int sB;        // slot step per output frame (1 for 1x1, else stride)
-    int LB;        // TIN*V
+    int LB;        // TIN*Vp
     int pitchB;    // LDS pitch of one channel row (== 16 mod 32)
+    // Joint geometry of the vectorised kernels.  A tile covers Vs joints per frame starting at joint v0 = slice*Vs of the
+    // V in HBM; its LDS line buffer gives every frame Vp floats.  Vs = Vp = V for the usual skeletons; V % 4 != 0 (NTU's
+    // 25 joints): Vp = V rounded up to 4, so that a 16-byte piece never straddles two frames of different validity (its
+    // last piece over-reads <= 3 floats of the next frame: callers guarantee 16 readable bytes behind an activation);
+    // large V with a temporal halo (V = 64): nsl = V/16 slices of Vs = 16 joints keep halo + tile within the line buffer.
+    int Vs, Vp, nsl;
 };
 
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[4][MAXCW], float* Ss, int n, int m0, int t0,
@@ -242,11 +248,16 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel(const ConvArgs a) {
 // 16-byte coalesced loads and stores.  Row moments land in Ss[0..BMT) / Ss[4*BM..).
 template <int NTH>
 __device__ __forceinline__ void staged_rows(const ConvArgs& a, const float* Tt, int PT, int RP, int r0, int BMT, int m0, int n, int t0,
-                                            int nc4, float* Ss) {
+                                            int ncols, float* Ss, int Vs, int v0) {
     const int tid = threadIdx.x, V = a.V;
     const int TPR = NTH / RP;
     const int row = tid / TPR, seg = tid - row * TPR;
     const int m = m0 + r0 + row;
+    // a group of four columns is ONE 16-byte access when its columns are consecutive in HBM: frames contiguous (full-width
+    // tile, unit output stride) or the group inside one frame (Vs % 4 == 0).  Row starts need not be 16-byte aligned
+    // (V = 25: rows of T*V floats; gfx950 takes dword-aligned dwordx4 accesses at full rate, tools/probes/unaligned_probe.hip).
+    const bool flat = Vs == V && a.ostride == 1;
+    const bool vecok = flat || (Vs & 3) == 0;
     float p1 = 0.f, p2 = 0.f;
     const bool rowok = r0 + row < BMT && m < a.M;   // RP may overshoot the tile (BMT = 48, RP = 32)
     if (rowok) {
@@ -255,44 +266,71 @@ __device__ __forceinline__ void staged_rows(const ConvArgs& a, const float* Tt, 
         const long long ybase = ((long long)n * a.yctot + a.ycoff + m) * a.T_y * V;
         const long long mbase = a.has_mask ? ((long long)n * a.mask.ctot + a.mask.coff + m) * a.T_y * V : 0;
         const long long abase = a.aux ? ((long long)n * a.auxctot + a.auxcoff + m) * a.T_y * V : 0;
+        const float* bc = a.bcast ? a.bcast + ((long long)m * a.N + n) * V : nullptr;
         float mc1 = 1.f, mc2 = 0.f, mc0 = 0.f;
         if (a.has_mask && a.mask.coef) {
             int mch = a.mask.coff + m;
             mc1 = a.mask.coef[mch]; mc0 = a.mask.coef[2 * a.mask.ctot + mch];
             if (a.mask.x2) mc2 = a.mask.coef[a.mask.ctot + mch];
         }
+        const int nc4 = (ncols + 3) >> 2;
         for (int c4 = seg; c4 < nc4; c4 += TPR) {
             const int col = c4 << 2;
-            const int fr = col / V, v = col - fr * V;
-            const long long off = (long long)(t0 + fr) * a.ostride * V + v;
-            float4 val = *reinterpret_cast<const float4*>(Tt + row * PT + col);
-            val.x += bia; val.y += bia; val.z += bia; val.w += bia;
-            if (a.bcast) {
-                float4 b = *reinterpret_cast<const float4*>(a.bcast + ((long long)m * a.N + n) * V + v);
-                val.x = fmaf(b.x, a.bcast_scale, val.x); val.y = fmaf(b.y, a.bcast_scale, val.y);
-                val.z = fmaf(b.z, a.bcast_scale, val.z); val.w = fmaf(b.w, a.bcast_scale, val.w);
-            }
-            if (a.add1) { float4 t = *reinterpret_cast<const float4*>(a.add1 + ybase + off); val.x += t.x; val.y += t.y; val.z += t.z; val.w += t.w; }
-            if (a.add2) { float4 t = *reinterpret_cast<const float4*>(a.add2 + ybase + off); val.x += t.x; val.y += t.y; val.z += t.z; val.w += t.w; }
-            if (a.has_mask) {
-                float4 q = *reinterpret_cast<const float4*>(a.mask.x1 + mbase + off);
-                float4 q2 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (a.mask.x2) q2 = *reinterpret_cast<const float4*>(a.mask.x2 + mbase + off);
-                if (!(fmaf(mc1, q.x, fmaf(mc2, q2.x, mc0)) > 0.f)) val.x = 0.f;
-                if (!(fmaf(mc1, q.y, fmaf(mc2, q2.y, mc0)) > 0.f)) val.y = 0.f;
-                if (!(fmaf(mc1, q.z, fmaf(mc2, q2.z, mc0)) > 0.f)) val.z = 0.f;
-                if (!(fmaf(mc1, q.w, fmaf(mc2, q2.w, mc0)) > 0.f)) val.w = 0.f;
-            }
-            if (a.stats_part) {
-                float4 x2 = val;
-                if (a.aux) {
-                    x2 = *reinterpret_cast<const float4*>(a.aux + abase + off);
-                    x2.x -= ctr; x2.y -= ctr; x2.z -= ctr; x2.w -= ctr;
+            const int fr = col / Vs, v = col - fr * Vs;
+            if (vecok && col + 4 <= ncols) {
+                const long long off = (long long)(t0 + fr) * a.ostride * V + v0 + v;
+                float4 val = *reinterpret_cast<const float4*>(Tt + row * PT + col);
+                val.x += bia; val.y += bia; val.z += bia; val.w += bia;
+                if (bc) {
+                    float4 b;
+                    if ((V & 3) == 0) b = *reinterpret_cast<const float4*>(bc + v0 + v);
+                    else { const int j0 = (v0 + v) % V; b = make_float4(bc[j0], bc[(j0 + 1) % V], bc[(j0 + 2) % V], bc[(j0 + 3) % V]); }
+                    val.x = fmaf(b.x, a.bcast_scale, val.x); val.y = fmaf(b.y, a.bcast_scale, val.y);
+                    val.z = fmaf(b.z, a.bcast_scale, val.z); val.w = fmaf(b.w, a.bcast_scale, val.w);
                 }
-                p1 += (val.x + val.y) + (val.z + val.w);
-                p2 = fmaf(val.x, x2.x, fmaf(val.y, x2.y, fmaf(val.z, x2.z, fmaf(val.w, x2.w, p2))));
+                if (a.add1) { float4 t = *reinterpret_cast<const float4*>(a.add1 + ybase + off); val.x += t.x; val.y += t.y; val.z += t.z; val.w += t.w; }
+                if (a.add2) { float4 t = *reinterpret_cast<const float4*>(a.add2 + ybase + off); val.x += t.x; val.y += t.y; val.z += t.z; val.w += t.w; }
+                if (a.has_mask) {
+                    float4 q = *reinterpret_cast<const float4*>(a.mask.x1 + mbase + off);
+                    float4 q2 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (a.mask.x2) q2 = *reinterpret_cast<const float4*>(a.mask.x2 + mbase + off);
+                    if (!(fmaf(mc1, q.x, fmaf(mc2, q2.x, mc0)) > 0.f)) val.x = 0.f;
+                    if (!(fmaf(mc1, q.y, fmaf(mc2, q2.y, mc0)) > 0.f)) val.y = 0.f;
+                    if (!(fmaf(mc1, q.z, fmaf(mc2, q2.z, mc0)) > 0.f)) val.z = 0.f;
+                    if (!(fmaf(mc1, q.w, fmaf(mc2, q2.w, mc0)) > 0.f)) val.w = 0.f;
+                }
+                if (a.stats_part) {
+                    float4 x2 = val;
+                    if (a.aux) {
+                        x2 = *reinterpret_cast<const float4*>(a.aux + abase + off);
+                        x2.x -= ctr; x2.y -= ctr; x2.z -= ctr; x2.w -= ctr;
+                    }
+                    p1 += (val.x + val.y) + (val.z + val.w);
+                    p2 = fmaf(val.x, x2.x, fmaf(val.y, x2.y, fmaf(val.z, x2.z, fmaf(val.w, x2.w, p2))));
+                }
+                *reinterpret_cast<float4*>(a.y + ybase + off) = val;
+            } else {
+                // the last, partial group of a tile whose column count is not a multiple of 4, or a group that leaves its
+                // frame in a strided / sliced output: one column at a time
+                for (int i = 0; i < 4 && col + i < ncols; ++i) {
+                    const int ci = col + i, fi = ci / Vs, vi = ci - fi * Vs;
+                    const long long off = (long long)(t0 + fi) * a.ostride * V + v0 + vi;
+                    float val = Tt[row * PT + ci] + bia;
+                    if (bc) val = fmaf(bc[(v0 + vi) % V], a.bcast_scale, val);
+                    if (a.add1) val += a.add1[ybase + off];
+                    if (a.add2) val += a.add2[ybase + off];
+                    if (a.has_mask) {
+                        const float q = a.mask.x1[mbase + off], q2 = a.mask.x2 ? a.mask.x2[mbase + off] : 0.f;
+                        if (!(fmaf(mc1, q, fmaf(mc2, q2, mc0)) > 0.f)) val = 0.f;
+                    }
+                    if (a.stats_part) {
+                        const float x2 = a.aux ? a.aux[abase + off] - ctr : val;
+                        p1 += val;
+                        p2 = fmaf(val, x2, p2);
+                    }
+                    a.y[ybase + off] = val;
+                }
             }
-            *reinterpret_cast<float4*>(a.y + ybase + off) = val;
         }
     }
     if (a.stats_part) {
@@ -314,10 +352,11 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel_vec(const ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kq = lane >> 4;
-    const int n = blockIdx.z, m0 = blockIdx.y * BMT, t0 = blockIdx.x * a.BT;
-    const int V = a.V;
+    const int tti = blockIdx.x / a.nsl, sl = blockIdx.x - tti * a.nsl;
+    const int n = blockIdx.z, m0 = blockIdx.y * BMT, t0 = tti * a.BT;
+    const int V = a.V, Vs = a.Vs, Vp = a.Vp, v0 = sl * Vs;
     const int bt = min(a.BT, a.T_out - t0);
-    const int ncols = bt * V;
+    const int ncols = bt * Vs;
     const int cw0 = wave * CWT;
 
     for (int e = tid; e < a.K; e += NTHREADS) {
@@ -331,7 +370,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel_vec(const ConvArgs a) {
 #pragma unroll
     for (int c = 0; c < CWT; ++c) {
         int col = (cw0 + c) * 16 + j;
-        if (col < ncols) { tl[c] = col / V; vv[c] = col - tl[c] * V; boff[c] = tl[c] * a.sB * V + vv[c]; }
+        if (col < ncols) { tl[c] = col / Vs; vv[c] = col - tl[c] * Vs; boff[c] = tl[c] * a.sB * Vp + vv[c]; }
         else { tl[c] = 0; vv[c] = 0; boff[c] = 0; }       // padding tile: reads in-bounds data, never stored
     }
     f32x4 acc[MT][CWT];
@@ -353,7 +392,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel_vec(const ConvArgs a) {
         int e = tid + i * NTHREADS;
         int kk = e / LB4, c4 = e - kk * LB4;
         int pos = c4 << 2;
-        int slot = pos / V, v = pos - slot * V;
+        int slot = pos / Vp, v = pos - slot * Vp;          // Vp == V: a piece may run on into the next frame (contiguous 1x1 form only)
         int th = tin0 + slot * a.lstride;
         bool ok = e < nvec && th >= 0;
         if (a.up > 1) { ok = ok && (th % a.up == 0); th /= a.up; }
@@ -361,7 +400,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel_vec(const ConvArgs a) {
         p_ok[i] = ok;
         p_kk[i] = e < nvec ? kk : -1;
         p_lds[i] = kk * a.pitchB + pos;
-        p_g[i] = (long long)n * a.src.ctot * chan_stride + (long long)(a.src.coff + kk) * chan_stride + (long long)th * V + v;
+        p_g[i] = (long long)n * a.src.ctot * chan_stride + (long long)(a.src.coff + kk) * chan_stride + (long long)th * V + v0 + v;
     }
     float4 r1[NPF], r2[NPF];
     const bool has2 = a.src.x2 != nullptr;
@@ -456,7 +495,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel_vec(const ConvArgs a) {
         TG_T(te); TG_ACC(5, te - td);
         for (int tap = 0; tap < a.KT; ++tap) {         // branch-free MFMA block: MT x CWT tiles per k-step
             const float* at = arow + tap * BMT * BKVP;
-            const float* bt_ = Bs + kq * a.pitchB + tap * a.dil * V;
+            const float* bt_ = Bs + kq * a.pitchB + tap * a.dil * Vp;
 #pragma unroll
             for (int k4 = 0; k4 < BKV / 4; ++k4) {
                 float av[MT], bv[CWT];
@@ -485,7 +524,6 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel_vec(const ConvArgs a) {
     int RP = (avail / PT) & ~15;                       // rows per pass: 16, 32, 48 or 64 (host checks >= 16)
     if (RP > BMT) RP = BMT;
     if (RP == 48) RP = 32;
-    const int nc4 = ncols >> 2;
     if (a.stats_part) {
         for (int e = tid; e < 2 * 4 * BM; e += NTHREADS) Ss[e] = 0.f;
     }
@@ -504,7 +542,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel_vec(const ConvArgs a) {
             }
         }
         __syncthreads();
-        staged_rows<NTHREADS>(a, Tt, PT, RP, r0, BMT, m0, n, t0, nc4, Ss);
+        staged_rows<NTHREADS>(a, Tt, PT, RP, r0, BMT, m0, n, t0, ncols, Ss, Vs, v0);
     }
     if (a.stats_part) {
         __syncthreads();
@@ -726,7 +764,6 @@ __global__ __launch_bounds__(G_NT, 2) void conv1x1_glds_kernel(const ConvArgs a,
     // ---- staged epilogue (two passes of 32 rows through the dead stage buffers)
     constexpr int PT = G_CWT * 64 + 4, RP = 32;
     float* Tt = smem;
-    const int nc4 = ncols >> 2;
     if (a.stats_part) {
         for (int e = tid; e < 2 * 4 * BM; e += G_NT) Ss[e] = 0.f;
     }
@@ -743,7 +780,7 @@ __global__ __launch_bounds__(G_NT, 2) void conv1x1_glds_kernel(const ConvArgs a,
                 }
         }
         __syncthreads();
-        staged_rows<G_NT>(a, Tt, PT, RP, r0, G_BMT, m0, n, t0, nc4, Ss);
+        staged_rows<G_NT>(a, Tt, PT, RP, r0, G_BMT, m0, n, t0, ncols, Ss, V, 0);
     }
     if (a.stats_part) {
         __syncthreads();
@@ -927,7 +964,6 @@ __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs
     // one column-wave per row group publishes it (Ss is free: this kernel produces no moments).
     constexpr int PT = G_CWT * 64 + 4, RP = 32;
     float* Tt = smem;
-    const int nc4 = ncols >> 2;
     float* Bc = Ss;                                               // [128] per-row constant
 #pragma unroll
     for (int mt = 0; mt < GS_MT; ++mt) {
@@ -952,7 +988,7 @@ __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs
                 }
         }
         __syncthreads();
-        staged_rows<G_NT>(a, Tt, PT, RP, r0, GS_BMT, m0, n, t0, nc4, Ss + 0);
+        staged_rows<G_NT>(a, Tt, PT, RP, r0, GS_BMT, m0, n, t0, ncols, Ss + 0, V, 0);
     }
 }
 
@@ -961,30 +997,42 @@ constexpr size_t glds_lds_bytes(int K) {
     return sizeof(float) * ((size_t)G_NST * (BK * G_PBMAX * NSRC + BK * G_PA) + 3 * (size_t)K + 2 * 4 * BM);
 }
 
-struct ConvPlan { int BT, CW, TIN, lstride, sB, LB, pitchB, ntt, bk, mt, cwt; bool vec; size_t lds; };
+struct ConvPlan { int BT, CW, TIN, lstride, sB, LB, pitchB, ntt, bk, mt, cwt, Vs, Vp, nsl; bool vec, flat; size_t lds; };
+
+static int gcd_i(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
 
 static int plan_conv(const tamgcn_conv_desc* d, ConvPlan* p) {
-    int V = d->V;
+    const int V = d->V;
     if (V < 1 || V > MAXCOLS) return -1;
-    const bool vec_ok = (V % 4 == 0) && d->K <= 1024;
-    int BT = MAXCOLS / V; if (BT < 1) BT = 1;
+    // contiguous 1x1 form: a channel row of the tile is one run of BT*V floats in HBM, whatever V is
+    p->flat = d->KT == 1 && d->stride == 1 && d->up == 1 && d->ostride == 1 && d->pad == 0 && d->T_in == d->T_out && d->T_y == d->T_out;
+    // joint slices for large skeletons with a temporal halo (V = 64: 8 halo frames are 512 floats per row, the tile 320)
+    p->Vs = V; p->nsl = 1;
+    if (!p->flat && d->KT > 1 && V > 32 && V % 16 == 0) { p->Vs = 16; p->nsl = V / 16; }
+    p->Vp = p->flat ? V : ((p->Vs + 3) & ~3);
+    const bool vec_try = d->K <= 1024 && (p->flat || (p->Vp & 3) == 0);
+    int BT = MAXCOLS / p->Vs; if (BT < 1) BT = 1;
     if (BT > d->T_out) BT = d->T_out;
+    const int q = 4 / gcd_i(V, 4);                          // flat tiles of V % 4 != 0: BT*V must be a multiple of 4
+    if (p->flat && q > 1 && BT >= q) BT -= BT % q;
     for (;;) {
         p->BT = BT;
         p->lstride = (d->KT == 1) ? d->stride : 1;
         p->sB = (d->KT == 1) ? 1 : d->stride;
         p->TIN = (d->KT == 1) ? BT : (BT - 1) * d->stride + (d->KT - 1) * d->dil + 1;
-        p->LB = p->TIN * V;
+        p->LB = p->TIN * p->Vp;
         int pitch = p->LB;
         pitch += ((16 - (pitch & 31)) + 32) & 31;          // pitch == 16 (mod 32)
         p->pitchB = pitch;
-        p->CW = ceil_div(ceil_div(BT * V, 16), 4);
+        p->CW = ceil_div(ceil_div(BT * p->Vs, 16), 4);
         p->vec = false; p->bk = BK;
-        if (vec_ok) {
+        bool slots_short = false;
+        if (vec_try && (p->LB & 3) == 0) {
             // BK = 32 when the activation chunk fits 10 float4 per thread, else 16 (8 per thread)
             int lb4 = p->LB / 4;
             int bk = (d->KT == 1 && 32 * lb4 <= 10 * NTHREADS) ? 32 : 16;
             if (bk * lb4 <= ((bk == 32) ? 10 : 8) * NTHREADS) { p->vec = true; p->bk = bk; }
+            else slots_short = true;
         }
         // output-channel tile: 16*mt rows, mt chosen so that M splits without a half-empty tile
         p->mt = d->M <= 16 ? 1 : d->M <= 32 ? 2 : (d->M % 64 == 0 ? 4 : (d->M % 48 == 0 ? 3 : 4));
@@ -996,9 +1044,16 @@ static int plan_conv(const tamgcn_conv_desc* d, ConvPlan* p) {
         p->lds = p->vec ? sizeof(float) * ((((size_t)d->KT * p->mt * 16 * (p->bk + 2) + 3) & ~(size_t)3) + (size_t)p->bk * pitch +
                                            2 * 4 * BM + 3 * (size_t)d->K)
                         : sizeof(float) * ((size_t)d->KT * BM * (BK + 1) + (size_t)BK * pitch + 2 * 4 * BM);
+        // a tile whose line buffer (frames + halo) exceeds the prefetch slots: fewer frames per tile rather than the scalar kernel
+        if (slots_short && BT > 1) { BT = BT > 4 ? BT - 2 : BT - 1; if (p->flat && q > 1 && BT >= q) BT -= BT % q; continue; }
         if (p->lds <= 64 * 1024 || BT == 1) break;
         BT = (BT + 1) / 2;
+        if (p->flat && q > 1 && BT >= q) BT -= BT % q;
     }
+    if (!p->vec) { p->Vs = V; p->nsl = 1; if (p->Vp != V) {           // scalar kernel: whole frames, pitch V
+        p->Vp = V; p->LB = p->TIN * V; int pitch = p->LB; pitch += ((16 - (pitch & 31)) + 32) & 31; p->pitchB = pitch;
+        p->CW = ceil_div(ceil_div(p->BT * V, 16), 4);
+        p->lds = sizeof(float) * ((size_t)d->KT * BM * (BK + 1) + (size_t)BK * pitch + 2 * 4 * BM); } }
     if (p->lds > 160 * 1024 || p->CW > MAXCW) return -1;
     p->ntt = ceil_div(d->T_out, p->BT);
     return 0;
@@ -1010,7 +1065,7 @@ static int plan_conv(const tamgcn_conv_desc* d, ConvPlan* p) {
 extern "C" int tamgcn_conv_nparts(const tamgcn_conv_desc* d) {
     ConvPlan p;
     if (!d || plan_conv(d, &p)) return -1;
-    return d->N * p.ntt;
+    return d->N * p.ntt * p.nsl;
 }
 
 extern "C" int tamgcn_conv(const tamgcn_conv_desc* d, void* stream) {
@@ -1038,13 +1093,13 @@ extern "C" int tamgcn_conv(const tamgcn_conv_desc* d, void* stream) {
     a.aux = d->aux; a.aux_center = d->aux_center; a.auxctot = d->auxctot; a.auxcoff = d->auxcoff;
     TG_CHECK(!d->aux || d->aux_center, "tamgcn_conv: aux needs aux_center");
     a.stats_part = d->stats_part; a.stats_ctot = d->stats_ctot; a.stats_coff = d->stats_coff;
-    a.nparts = d->N * p.ntt;
+    a.nparts = d->N * p.ntt * p.nsl;
     a.BT = p.BT; a.CW = p.CW; a.TIN = p.TIN; a.lstride = p.lstride; a.sB = p.sB; a.LB = p.LB; a.pitchB = p.pitchB;
+    a.Vs = p.Vs; a.Vp = p.Vp; a.nsl = p.nsl;
     dim3 grid(p.ntt, ceil_div(d->M, BM), d->N);
     // 1x1 stride-1 convs whose rows are plain contiguous column ranges go to the LDS-DMA GEMM
     const bool aligned16 = (((uintptr_t)d->src.x1 | (uintptr_t)(d->src.x2 ? d->src.x2 : d->src.x1) | (uintptr_t)d->w) & 15) == 0;
-    const bool glds = p.vec && d->KT == 1 && d->stride == 1 && d->up == 1 && d->ostride == 1 && d->pad == 0 &&
-                      d->T_in == d->T_out && d->T_y == d->T_out && d->K % 16 == 0 && p.LB >= 64 && p.LB <= G_PBMAX &&
+    const bool glds = p.vec && p.flat && d->K % 16 == 0 && p.LB >= 64 && p.LB <= G_PBMAX && (p.LB & 3) == 0 &&
                       aligned16 && (long long)d->K * d->T_in * d->V < (1LL << 30);
     const bool big = glds && tamgcn_split_mode() >= 1 && d->wmode == 1 && d->src.act == 0 && d->M >= 128 && d->M % 4 == 0 &&
                      d->K % GS_BK == 0 && !d->stats_part;
@@ -1074,7 +1129,7 @@ extern "C" int tamgcn_conv(const tamgcn_conv_desc* d, void* stream) {
             tamgcn_note_kernel("conv1x1_glds_kernel<1, 16>");
         }
     } else if (p.vec) {
-        dim3 gridv(p.ntt, ceil_div(d->M, 16 * p.mt), d->N);
+        dim3 gridv(p.ntt * p.nsl, ceil_div(d->M, 16 * p.mt), d->N);
 #define TG_CONV_CASE(BKV_, MT_, CW_)                                                                              \
         if (p.bk == BKV_ && p.mt == MT_ && p.cwt == CW_) {                                                         \
             if (p.lds > 64 * 1024)                                                                                 \
@@ -1553,6 +1608,34 @@ __global__ __launch_bounds__(W_NT, 2) void wgrad_glds_kernel(const WgradArgs a, 
             }
 }
 
+// The contraction elements the LDS-DMA kernel leaves over when a row (T*V floats) is not a multiple of its 32-element
+// chunk (V = 25: 7500 = 234 * 32 + 12): dW_tail[m][k] = sum_n sum_{p >= cps*32} gy(n, m, p) * x(n, k, p), written as
+// one more partial slab.  16 x 16 outputs per workgroup, the <= 31 tail elements of the 32 rows staged per sample.
+__global__ __launch_bounds__(256) void wgrad_tail_kernel(const WgradArgs a, int p0, int ntail, float* out) {
+    __shared__ float Ys[16][32], Xs[16][32];
+    const int tid = threadIdx.x, mi = tid >> 4, ki = tid & 15;
+    const int m0 = blockIdx.y * 16, k0 = blockIdx.x * 16;
+    const long long cs = (long long)a.T_out * a.V;
+    float acc = 0.f;
+    for (int n = 0; n < a.N; ++n) {
+        __syncthreads();
+        for (int e = tid; e < 2 * 16 * ntail; e += 256) {
+            const int which = e / (16 * ntail), r = (e / ntail) & 15, p = e % ntail;
+            const SrcDev& sd = which ? a.src : a.gy;
+            const int ch = (which ? k0 : m0) + r;
+            float v = 0.f;
+            if (ch < (which ? a.K : a.M)) {
+                const int c = sd.coff + ch;
+                v = src_value(sd, ((long long)n * sd.ctot + c) * cs + p0 + p, c);
+            }
+            (which ? Xs : Ys)[r][p] = v;
+        }
+        __syncthreads();
+        for (int p = 0; p < ntail; ++p) acc = fmaf(Ys[mi][p], Xs[ki][p], acc);
+    }
+    if (m0 + mi < a.M && k0 + ki < a.K) out[(long long)(m0 + mi) * a.K + k0 + ki] = acc;
+}
+
 template <int WMT, int WKT, int NY, int NX, bool SPL>
 static int launch_wgrad_glds(WgradArgs& a, hipStream_t s) {
     constexpr int BMW = 2 * WMT * 16, BKW = 4 * WKT * 16;
@@ -1562,9 +1645,16 @@ static int launch_wgrad_glds(WgradArgs& a, hipStream_t s) {
     const size_t lds = NST * STAGE;
     static tg_devmask flag = 0;
     tg_allow_lds((const void*)wgrad_glds_kernel<WMT, WKT, NY, NX, SPL, NST>, 160 * 1024, &flag);
-    a.n_per = ceil_div(a.N * (int)(((long long)a.T_out * a.V) / W_PC), a.nsplit);   // chunks per split
+    const long long cs = (long long)a.T_out * a.V;
+    const int cps = (int)(cs / W_PC), ntail = (int)(cs - (long long)cps * W_PC);
+    const int nsplit_all = a.nsplit;
+    if (ntail) a.nsplit = nsplit_all - 1;                         // the last slab belongs to the tail kernel (host checked nsplit >= 2)
+    a.n_per = ceil_div(a.N * cps, a.nsplit);                      // chunks per split
     const int ntk = ceil_div(a.K, BKW), ntm = ceil_div(a.M, BMW);
     hipLaunchKernelGGL((wgrad_glds_kernel<WMT, WKT, NY, NX, SPL, NST>), dim3((unsigned)(ntk * ntm * a.nsplit)), dim3(W_NT), lds, s, a, ntk, ntm);
+    if (ntail)
+        hipLaunchKernelGGL(wgrad_tail_kernel, dim3(ceil_div(a.K, 16), ceil_div(a.M, 16)), dim3(256), 0, s, a, cps * W_PC, ntail,
+                           a.part + (long long)(nsplit_all - 1) * a.M * a.K);
     tamgcn_note_kernel("wgrad_glds_kernel<%d, %d, %d, %d, %s, %d>", WMT, WKT, NY, NX, SPL ? "split" : "f32", NST);
     return 0;
 }
@@ -1661,8 +1751,9 @@ static bool wgrad_glds_plan(const tamgcn_wgrad_desc* d, int* wmt, int* wkt) {
     wgrad_tile(d->M, d->K, d->KT, wmt, wkt);
     const bool al16 = (((uintptr_t)d->gy.x1 | (uintptr_t)d->src.x1 | (uintptr_t)(d->gy.x2 ? d->gy.x2 : d->gy.x1) |
                         (uintptr_t)(d->src.x2 ? d->src.x2 : d->src.x1)) & 15) == 0;
+    // rows whose length is not a multiple of the 32-element chunk leave a tail to wgrad_tail_kernel (one more slab)
     bool glds = d->KT == 1 && d->stride == 1 && d->pad == 0 && d->T_in == d->T_out && al16 &&
-                ((long long)d->T_out * d->V) % W_PC == 0;
+                (long long)d->T_out * d->V >= 2 * W_PC && (((long long)d->T_out * d->V) % W_PC == 0 || d->nsplit != 1);
     if (!glds) return false;
     // three stages of both operands (every source) must fit the CU's LDS: shrink the tile
     auto fits = [&](int tm, int tk) {

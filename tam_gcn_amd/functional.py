@@ -272,7 +272,7 @@ def tcn_forward(g, P, training, save, xres=None):
     Ch = (nb + 1) * Cb
     fk = Fork(g.device, 2)
     fk.__enter__()
-    cat_pre = torch.empty(N, Cout, T2, V, device=g.device)
+    cat_pre = ops.empty(N, Cout, T2, V, like=g)
     coef_c, save_c = _coef(Cout, g)
     with fk.on(1):                                     # the plain 1x1 branch only needs g
         _, lpart = ops.conv(gs, K=Cin, w=P.Wl, bias=P.bl, M=Cb, stride=s, y=cat_pre, ycoff=(nb + 1) * Cb, T_out=T2,
@@ -353,7 +353,7 @@ def _tcn_backward(P, sv, dout, need_dg=True, need_dxres=True):
     def gcat(coff):
         return S(dz, cat_pre, coefb_c, coff=coff)
 
-    dh = torch.empty(N, Ch, T, V, device=g.device)
+    dh = ops.empty(N, Ch, T, V, like=g)
     coefb_h = torch.empty(3, Ch, device=g.device)
     G['Wt'] = []
     G['bn_in'] = []
@@ -412,7 +412,7 @@ def _tcn_backward(P, sv, dout, need_dg=True, need_dxres=True):
         if need_dxres:
             Tx = xres.shape[2]
             if rk == 1:
-                dxres = torch.zeros_like(xres) if s > 1 else torch.empty_like(xres)
+                dxres = ops.zeros_like(xres) if s > 1 else ops.empty_like(xres)
                 ops.conv(gyr, K=Cout, w=P.Wr, bias=None, M=xres.shape[1], wmode=1, y=dxres, T_out=T2, ostride=s)
             else:
                 dxres, _ = ops.conv(gyr, K=Cout, w=P.Wr, bias=None, M=xres.shape[1], KT=rk, stride=1,
@@ -564,7 +564,7 @@ class ConvBNFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[1]:
             if k == 1:
-                dx = torch.zeros_like(x) if s > 1 else torch.empty_like(x)
+                dx = ops.zeros_like(x) if s > 1 else ops.empty_like(x)
                 ops.conv(gy, K=M, w=w, bias=None, M=Cin, wmode=1, y=dx, T_out=T2, ostride=s)
             else:
                 dx, _ = ops.conv(gy, K=M, w=w, bias=None, M=Cin, KT=k, dil=d, stride=1, pad=(k - 1) * d - pad,
@@ -761,7 +761,7 @@ class StGcnFn(torch.autograd.Function):
                 dwr = ops.wgrad(gyr, xs, M=Cout, K=Cin, KT=1, stride=s, pad=0)
                 gres = [dwr, dbr, dgr, dber]
                 if need_dx:
-                    add1 = torch.zeros_like(x) if s > 1 else torch.empty_like(x)
+                    add1 = ops.zeros_like(x) if s > 1 else ops.empty_like(x)
                     ops.conv(gyr, K=Cout, w=wr, bias=None, M=Cin, wmode=1, y=add1, T_out=T2, ostride=s)
             dx = None
             if need_dx:

@@ -63,8 +63,37 @@ def _slice_src(src, n0, n1):
     return S(src.x1[n0:n1], None if src.x2 is None else src.x2[n0:n1], src.coef, src.coff, src.act)
 
 
+SLACK = 4          # floats readable behind every activation the ops allocate (see with_slack)
+
+
 def empty(*shape, like):
-    return torch.empty(shape, device=like.device, dtype=torch.float32)
+    """fp32 tensor on like's device with SLACK floats of readable memory behind its last element."""
+    n = 1
+    for d_ in shape:
+        n *= d_
+    return torch.empty(n + SLACK, device=like.device, dtype=torch.float32)[:n].view(shape)
+
+
+def empty_like(t):
+    return empty(*t.shape, like=t)
+
+
+def zeros_like(t):
+    return empty(*t.shape, like=t).zero_()
+
+
+def with_slack(t):
+    """The 16-byte kernels may read up to 12 bytes past the last element of an activation whose rows (V joints) are not
+    a multiple of 4 floats (the last 16-byte piece of the last frame).  Tensors from empty() carry that slack; a tensor
+    that ends exactly at the end of its storage (a caller's input, an autograd-made gradient) is copied once."""
+    if t is None or t.shape[-1] % 4 == 0:
+        return t
+    st = t.untyped_storage()
+    if st.nbytes() - (t.storage_offset() + t.numel()) * t.element_size() >= 4 * SLACK:
+        return t
+    out = empty(*t.shape, like=t)
+    out.copy_(t)
+    return out
 
 
 # ---------------------------------------------------------------------------
@@ -72,6 +101,8 @@ def conv(src, K, w, bias, M, KT=1, dil=1, stride=1, pad=0, wmode=0, up=1,
          y=None, ycoff=0, T_out=None, T_y=None, ostride=1, add1=None, add2=None,
          bcast=None, bcast_scale=0.0, mask=None, aux=None, aux_center=None, auxcoff=0, stats=False):
     """y (N, yctot, T_y, V); returns (y, stats_part [2][yctot][nparts] or None)."""
+    if src.x1.shape[-1] % 4:
+        src = S(with_slack(src.x1), with_slack(src.x2), src.coef, src.coff, src.act)
     x = src.x1
     N, _, T_in, V = x.shape
     if T_out is None:
@@ -427,7 +458,7 @@ def gcn_tail_fwd(y, o, res):
 
 def gcn_tail_bwd(dg, g, o, o_save):
     N, Cc, T, V = g.shape
-    dsum, doz = torch.empty_like(g), torch.empty_like(g)
+    dsum, doz = empty_like(g), empty_like(g)
     part = empty(2, Cc, N, like=g)
     oc = o.c()
     _lib.check(_lib_().tamgcn_gcn_tail_bwd(_ptr(dg), _ptr(g), C.byref(oc), _ptr(o_save), N, Cc, T, V, _ptr(dsum), _ptr(doz),
@@ -437,8 +468,8 @@ def gcn_tail_bwd(dg, g, o, o_save):
 
 def gcn_mid_bwd(dsum, ddiff, y_pre, y_save, r_pre, r_save, want_dres):
     N, Cc, T, V = dsum.shape
-    dyb = torch.empty_like(dsum)
-    dres = torch.empty_like(dsum) if want_dres else None
+    dyb = empty_like(dsum)
+    dres = empty_like(dsum) if want_dres else None
     part = empty(4 if r_pre is not None else 2, Cc, N, like=dsum)
     _lib.check(_lib_().tamgcn_gcn_mid_bwd(_ptr(dsum), _ptr(ddiff), _ptr(y_pre), _ptr(y_save), _ptr(r_pre), _ptr(r_save), N, Cc, T, V,
                                           _ptr(dyb), _ptr(dres), _ptr(part), _stream()), 'tamgcn_gcn_mid_bwd')
@@ -477,7 +508,7 @@ def add_act_fwd(a, res, relu, C_):
 
 def add_act_bwd(dout, out, relu, a_pre, a_save, r_pre, r_save, want_dz):
     N, Cc, T, V = dout.shape
-    dz = torch.empty_like(dout) if want_dz else None
+    dz = empty_like(dout) if want_dz else None
     part = empty(4 if r_pre is not None else 2, Cc, N, like=dout)
     _lib.check(_lib_().tamgcn_add_act_bwd(_ptr(dout), _ptr(out), int(relu), _ptr(a_pre), _ptr(a_save), _ptr(r_pre), _ptr(r_save), N, Cc, T, V,
                                           _ptr(dz), _ptr(part), _stream()), 'tamgcn_add_act_bwd')

@@ -9,7 +9,8 @@ fp32 rounding level:
 
     forward          max-abs error <= 5e-6 * max|ref|
     gradients        max-abs error <= REL_G * max|ref|, REL_G = 1e-5 with exact fp32 GEMMs (TAMGCN_SPLIT_BF16=0) and
-                     3e-5 in the default mode, whose backward GEMMs are 2-term bf16 splits (4.5e-6 relative per GEMM)
+                     3e-5 in the default mode, whose backward GEMMs are 2-term bf16 splits (4.5e-6 relative per GEMM;
+                     1e-4 for per-channel vectors there, REL_VEC_SPLIT)
 
 A real 1 % bug in any backward kernel of l6-l10 fails this test by three orders of magnitude.  Both arithmetic modes
 run (the switch is the C ABI's tamgcn_set_split_mode).
@@ -36,6 +37,10 @@ from oracle import ctrgcn_oracle as O                                           
 REL_Y = 5e-6
 REL_G = {0: 1e-5, 1: 3e-5}
 BLOCK_CASES = ('ucla_t64', 'ntu_t20')
+# per-channel vectors (BatchNorm beta / gamma, conv biases) in the split mode: plain sums over every position of a gradient
+# tensor that carries the 2-term split's 4.5e-6 relative error per element; with the sum's own cancellation (~10x at the
+# 250-position NTU case) up to 6e-5 of max|ref| was measured, the exact mode holds 1e-5 on the same tensors
+REL_VEC_SPLIT = 1e-4
 REL_SCALAR = 5e-4
 # gamma of the max-pool branch's entry BatchNorm: the branch ends in another train-mode BatchNorm, which removes the
 # scale gamma sets (exactly, for beta = 0 and eps = 0), so d gamma is a nearly cancelling sum whose value is ~1e-2 of
@@ -194,6 +199,8 @@ def test_every_block_teacher_forced(tag, mode, traces, teachers):
                     continue
                 e = _rel(p.grad, ref)
                 bar = REL_G[mode]
+                if mode == 1 and p.dim() == 1:
+                    bar = REL_VEC_SPLIT                    # see REL_VEC_SPLIT
                 if p.numel() == 1:
                     bar = REL_SCALAR                       # unit_gcn.alpha: ONE heavily cancelling sum over every (n, s, c, u, v)
                 elif k == 'tcn1.branches.2.1.weight':
