@@ -86,71 +86,128 @@ __global__ __launch_bounds__(512) void ctrgc_E_tiled_kernel(const ETArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// aggregation, forward: workgroup = (n, c)
+// The three streaming kernels below are generic in (V, VP): V joints in HBM, VP = V rounded up to a multiple of 16 in LDS
+// (zero padding), so that skeletons that do not tile into 16x16 MFMA shapes run on the same code: NTU's V = 25 as VP = 32
+// (78 % of the matrix work is real; the kernels are HBM-bound).  Rows of V floats need no alignment (16-byte accesses from
+// dword-aligned addresses run at full rate on gfx950, tools/probes/unaligned_probe.hip); a row's last 16-byte piece may read
+// <= 12 bytes into the next row: x3 / E / dy come from the ops' allocator, which keeps that slack behind every tensor.
 // ---------------------------------------------------------------------------------------------------------------
-// E_c of every subset -> LDS, rows u (TRANSPOSE = false: Es[s][u][v]) or rows v (true: Es[s][v][u]), pitch V + 2
+template <int V> struct TlGeo {
+    static constexpr int VP = (V + 15) & ~15;          // joints in LDS
+    static constexpr int PE = VP + 2;                  // A-type pitch
+    static constexpr int K4 = (V + 3) / 4;             // contraction steps over joints (pads are zero)
+    static constexpr int NUT = VP / 16;                // 16-wide joint tiles
+    static constexpr bool AL = (V % 4) == 0;
+};
+
+// float4 of a contiguous [rows][V] run starting at flat index f -> LDS image with row pitch P (rows of V real + zero pads)
+template <int V>
+__device__ __forceinline__ void scatter4(float* img, int P, int f, const float4& t) {
+    if constexpr ((V & 3) == 0) {
+        const int r = f / V, c = f - r * V;
+        float2* d = reinterpret_cast<float2*>(img + r * P + c);
+        d[0] = make_float2(t.x, t.y);
+        d[1] = make_float2(t.z, t.w);
+    } else {
+        const float vals[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int r = (f + k) / V, c = (f + k) - r * V; img[r * P + c] = vals[k]; }
+    }
+}
+
+// E_c of every subset -> LDS, rows u (TRANSPOSE = false: Es[s][u][v]) or rows v (true: Es[s][v][u]), pitch VP + 2, pads zero
 template <int V, int ST, bool TRANSPOSE>
 __device__ __forceinline__ void stage_E(const float* __restrict__ Eg, int Cout, int n, int c, float* Es) {
-    constexpr int VV = V * V, PE = V + 2, NV4 = ST * VV / 4, NL = NV4 / 256;
-    static_assert(NV4 % 256 == 0, "E tile is a whole number of 256-thread float4 sweeps");
-    float4 t[NL];
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-        const int e = threadIdx.x + i * 256, s = e / (VV / 4), r = e - s * (VV / 4);
-        t[i] = reinterpret_cast<const float4*>(Eg + (((long long)n * ST + s) * Cout + c) * VV)[r];
+    using G = TlGeo<V>;
+    constexpr int VV = V * V, PE = G::PE, VP = G::VP;
+    if constexpr (VP != V) {
+        for (int e = threadIdx.x; e < ST * VP * PE; e += 256) Es[e] = 0.f;
+        __syncthreads();
     }
+    if constexpr (G::AL) {
+        constexpr int NV4 = ST * VV / 4, NL = (NV4 + 255) / 256;
+        float4 t[NL];
 #pragma unroll
-    for (int i = 0; i < NL; ++i) {
-        const int e = threadIdx.x + i * 256, s = e / (VV / 4), r = e - s * (VV / 4);
-        const int u = (r * 4) / V, v = (r * 4) - u * V;
-        if constexpr (!TRANSPOSE) {
-            float2* d = reinterpret_cast<float2*>(Es + (s * V + u) * PE + v);
-            d[0] = make_float2(t[i].x, t[i].y);
-            d[1] = make_float2(t[i].z, t[i].w);
-        } else {
-            float* d = Es + (s * V + v) * PE + u;
-            d[0] = t[i].x; d[PE] = t[i].y; d[2 * PE] = t[i].z; d[3 * PE] = t[i].w;
+        for (int i = 0; i < NL; ++i) {
+            const int e = threadIdx.x + i * 256, ec = e < NV4 ? e : 0, s = ec / (VV / 4), r = ec - s * (VV / 4);
+            t[i] = reinterpret_cast<const float4*>(Eg + (((long long)n * ST + s) * Cout + c) * VV)[r];
+        }
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int e = threadIdx.x + i * 256, s = e / (VV / 4), r = e - s * (VV / 4);
+            if (e < NV4) {
+                const int u = (r * 4) / V, v = (r * 4) - u * V;
+                if constexpr (!TRANSPOSE) {
+                    float2* d = reinterpret_cast<float2*>(Es + (s * VP + u) * PE + v);
+                    d[0] = make_float2(t[i].x, t[i].y);
+                    d[1] = make_float2(t[i].z, t[i].w);
+                } else {
+                    float* d = Es + (s * VP + v) * PE + u;
+                    d[0] = t[i].x; d[PE] = t[i].y; d[2 * PE] = t[i].z; d[3 * PE] = t[i].w;
+                }
+            }
+        }
+    } else {
+        constexpr int NE = ST * VV, NL = (NE + 255) / 256;
+        float t[NL];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int e = threadIdx.x + i * 256, ec = e < NE ? e : 0, s = ec / VV, r = ec - s * VV;
+            t[i] = Eg[(((long long)n * ST + s) * Cout + c) * VV + r];
+        }
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int e = threadIdx.x + i * 256, s = e / VV, r = e - s * VV;
+            if (e < NE) {
+                const int u = r / V, v = r - u * V;
+                Es[TRANSPOSE ? (s * VP + v) * PE + u : (s * VP + u) * PE + v] = t[i];
+            }
         }
     }
 }
 
+// aggregation, forward: workgroup = (n, c)
 template <int V, int ST>
 __global__ __launch_bounds__(256, 2) void ctrgc_agg_fwd_kernel(int N, int Cout, int T, const float* __restrict__ x3, const float* __restrict__ E,
                                                                float* __restrict__ y, float* __restrict__ stats_part) {
-    constexpr int PE = V + 2, NUT = V / 16, UW = NUT / 2, BT = TL_BT, NPF = ST * BT * V / 4 / 256;
-    static_assert(V % 32 == 0 && (ST * BT * V / 4) % 256 == 0, "tile geometry");
+    using G = TlGeo<V>;
+    constexpr int PE = G::PE, VP = G::VP, UW = G::NUT / 2, BT = TL_BT, CH4 = BT * V / 4, NPF = (ST * CH4 + 255) / 256;
+    static_assert(G::NUT % 2 == 0 && (BT * V) % 4 == 0, "tile geometry");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float red[2][4];
-    float* Es = smem;                         // [ST][V][PE]
-    float* Xs = Es + ST * V * PE;             // [ST][BT][PE]
+    float* Es = smem;                         // [ST][VP][PE]
+    float* Xs = Es + ST * VP * PE;            // [ST][BT][PE]
     const int n = blockIdx.x / Cout, c = blockIdx.x - n * Cout;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kq = lane >> 4;
     const int tt = wave >> 1, ub = (wave & 1) * UW;
     const long long TV = (long long)T * V;
+    if constexpr (VP != V) for (int e = tid; e < ST * BT * PE; e += 256) Xs[e] = 0.f;     // joint pads stay zero
     stage_E<V, ST, false>(E, Cout, n, c, Es);
 
     float4 pre[NPF];
     auto prefetch = [&](int t0) {
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
-            const int e = tid + i * 256, s = e / (BT * V / 4), r = e - s * (BT * V / 4);
-            const int t = t0 + (r * 4) / V;
-            pre[i] = t < T ? reinterpret_cast<const float4*>(x3 + (((long long)n * ST + s) * Cout + c) * TV + (long long)t0 * V)[r]
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int e = tid + i * 256, ec = e < ST * CH4 ? e : 0, s = ec / CH4, r = ec - s * CH4;
+            const bool ok = e < ST * CH4 && t0 + (r * 4) / V < T;
+            pre[i] = ok ? reinterpret_cast<const float4*>(x3 + (((long long)n * ST + s) * Cout + c) * TV + (long long)t0 * V)[r]
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     prefetch(0);
     float s1 = 0.f, s2 = 0.f;
     float* yrow = y + ((long long)n * Cout + c) * TV;
     for (int t0 = 0; t0 < T; t0 += BT) {
-        __syncthreads();                      // previous chunk's MFMAs are done with Xs (first pass: E staged)
-#pragma unroll
+        __syncthreads();                      // previous chunk's MFMAs are done with Xs (first pass: E staged, pads zeroed)
+        const int valid = min(BT, T - t0) * V;   // a piece that starts inside the clip may run past its end: those floats belong to
+#pragma unroll                                   // the next row and must not enter the sum: cut per element
         for (int i = 0; i < NPF; ++i) {
-            const int e = tid + i * 256, s = e / (BT * V / 4), r = e - s * (BT * V / 4);
-            const int tl = (r * 4) / V, v = (r * 4) - tl * V;
-            float2* d = reinterpret_cast<float2*>(Xs + (s * BT + tl) * PE + v);
-            d[0] = make_float2(pre[i].x, pre[i].y);
-            d[1] = make_float2(pre[i].z, pre[i].w);
+            const int e = tid + i * 256, s = e / CH4, r = e - s * CH4;
+            if (e < ST * CH4) {
+                float4 t = pre[i];
+                if (r * 4 + 3 >= valid) { if (r * 4 + 0 >= valid) t.x = 0.f; if (r * 4 + 1 >= valid) t.y = 0.f; if (r * 4 + 2 >= valid) t.z = 0.f; t.w = 0.f; }
+                scatter4<V>(Xs + s * BT * PE, PE, r * 4, t);
+            }
         }
         __syncthreads();
         if (t0 + BT < T) prefetch(t0 + BT);   // in flight under the MFMAs
@@ -160,9 +217,9 @@ __global__ __launch_bounds__(256, 2) void ctrgc_agg_fwd_kernel(int N, int Cout, 
 #pragma unroll
         for (int s = 0; s < ST; ++s) {
             const float* ar = Xs + (s * BT + tt * 16 + j) * PE + kq;
-            const float* br = Es + (s * V + ub * 16 + j) * PE + kq;
+            const float* br = Es + (s * VP + ub * 16 + j) * PE + kq;
 #pragma unroll
-            for (int k4 = 0; k4 < V / 4; ++k4) {
+            for (int k4 = 0; k4 < G::K4; ++k4) {
                 const float av = ar[k4 * 4];
 #pragma unroll
                 for (int u = 0; u < UW; ++u) acc[u] = mfma16(av, br[u * 16 * PE + k4 * 4], acc[u]);
@@ -174,10 +231,13 @@ __global__ __launch_bounds__(256, 2) void ctrgc_agg_fwd_kernel(int N, int Cout, 
             if (t < T) {
 #pragma unroll
                 for (int u = 0; u < UW; ++u) {
-                    const float v = acc[u][r];
-                    yrow[(long long)t * V + (ub + u) * 16 + j] = v;
-                    s1 += v;
-                    s2 = fmaf(v, v, s2);
+                    const int uu = (ub + u) * 16 + j;
+                    if (VP == V || uu < V) {
+                        const float v = acc[u][r];
+                        yrow[(long long)t * V + uu] = v;
+                        s1 += v;
+                        s2 = fmaf(v, v, s2);
+                    }
                 }
             }
         }
@@ -190,22 +250,22 @@ __global__ __launch_bounds__(256, 2) void ctrgc_agg_fwd_kernel(int N, int Cout, 
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
 // aggregation, backward w.r.t. x3: dx3_s[t][v] = sum_u dy[t][u] E_s[u][v]
-// ---------------------------------------------------------------------------------------------------------------
 template <int V, int ST>
 __global__ __launch_bounds__(256, 2) void ctrgc_agg_bwd_kernel(int N, int Cout, int T, const SrcDev dy, const float* __restrict__ E,
                                                                float* __restrict__ dx3, float* __restrict__ db3_part) {
-    constexpr int PE = V + 2, NUT = V / 16, VW = NUT / 2, BT = TL_BT, NPF = BT * V / 4 / 256;
-    static_assert(V % 32 == 0 && (BT * V / 4) % 256 == 0, "tile geometry");
+    using G = TlGeo<V>;
+    constexpr int PE = G::PE, VP = G::VP, VW = G::NUT / 2, BT = TL_BT, CH4 = BT * V / 4, NPF = (CH4 + 255) / 256;
+    static_assert(G::NUT % 2 == 0 && (BT * V) % 4 == 0, "tile geometry");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float red[ST][4];
     float* Es = smem;                         // [ST][v][PE] (transposed)
-    float* Zs = Es + ST * V * PE;             // [BT][PE]
+    float* Zs = Es + ST * VP * PE;            // [BT][PE]
     const int n = blockIdx.x / Cout, c = blockIdx.x - n * Cout;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kq = lane >> 4;
     const int tt = wave >> 1, vb = (wave & 1) * VW;
     const long long TV = (long long)T * V;
+    if constexpr (VP != V) for (int e = tid; e < BT * PE; e += 256) Zs[e] = 0.f;
     stage_E<V, ST, true>(E, Cout, n, c, Es);
     const int ch = dy.coff + c;
     const float c1 = dy.coef ? dy.coef[ch] : 1.f;
@@ -218,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void ctrgc_agg_bwd_kernel(int N, int Cout, 
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
             const int r = tid + i * 256;
-            const bool ok = t0 + (r * 4) / V < T;
+            const bool ok = r < CH4 && t0 + (r * 4) / V < T;
             p1[i] = ok ? reinterpret_cast<const float4*>(dy.x1 + dyb + (long long)t0 * V)[r] : make_float4(0.f, 0.f, 0.f, 0.f);
             p2[i] = (ok && dy.x2) ? reinterpret_cast<const float4*>(dy.x2 + dyb + (long long)t0 * V)[r] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -229,18 +289,20 @@ __global__ __launch_bounds__(256, 2) void ctrgc_agg_bwd_kernel(int N, int Cout, 
     for (int s = 0; s < ST; ++s) sb[s] = 0.f;
     for (int t0 = 0; t0 < T; t0 += BT) {
         __syncthreads();
+        const int valid = min(BT, T - t0) * V;
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
             const int r = tid + i * 256;
-            const int tl = (r * 4) / V, u = (r * 4) - tl * V;
-            const bool ok = t0 + tl < T;                       // rows past T are zero (the prologue's constant must not leak in)
-            float o[4] = {fmaf(c1, p1[i].x, fmaf(c2, p2[i].x, c0)), fmaf(c1, p1[i].y, fmaf(c2, p2[i].y, c0)),
-                          fmaf(c1, p1[i].z, fmaf(c2, p2[i].z, c0)), fmaf(c1, p1[i].w, fmaf(c2, p2[i].w, c0))};
+            if (r < CH4) {
+                float o[4] = {fmaf(c1, p1[i].x, fmaf(c2, p2[i].x, c0)), fmaf(c1, p1[i].y, fmaf(c2, p2[i].y, c0)),
+                              fmaf(c1, p1[i].z, fmaf(c2, p2[i].z, c0)), fmaf(c1, p1[i].w, fmaf(c2, p2[i].w, c0))};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { if (dy.act == 1) o[k] = fmaxf(o[k], 0.f); if (!ok) o[k] = 0.f; }
-            float2* d = reinterpret_cast<float2*>(Zs + tl * PE + u);
-            d[0] = make_float2(o[0], o[1]);
-            d[1] = make_float2(o[2], o[3]);
+                for (int k = 0; k < 4; ++k) {       // rows past T are zero (the prologue's constant must not leak in)
+                    if (dy.act == 1) o[k] = fmaxf(o[k], 0.f);
+                    if (r * 4 + k >= valid) o[k] = 0.f;
+                }
+                scatter4<V>(Zs, PE, r * 4, make_float4(o[0], o[1], o[2], o[3]));
+            }
         }
         __syncthreads();
         if (t0 + BT < T) prefetch(t0 + BT);
@@ -251,12 +313,12 @@ __global__ __launch_bounds__(256, 2) void ctrgc_agg_bwd_kernel(int N, int Cout, 
             for (int v = 0; v < VW; ++v) acc[s][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const float* ar = Zs + (tt * 16 + j) * PE + kq;
 #pragma unroll
-        for (int k4 = 0; k4 < V / 4; ++k4) {
+        for (int k4 = 0; k4 < G::K4; ++k4) {
             const float av = ar[k4 * 4];
 #pragma unroll
             for (int s = 0; s < ST; ++s)
 #pragma unroll
-                for (int v = 0; v < VW; ++v) acc[s][v] = mfma16(av, Es[(s * V + (vb + v) * 16 + j) * PE + k4 * 4 + kq], acc[s][v]);
+                for (int v = 0; v < VW; ++v) acc[s][v] = mfma16(av, Es[(s * VP + (vb + v) * 16 + j) * PE + k4 * 4 + kq], acc[s][v]);
         }
 #pragma unroll
         for (int s = 0; s < ST; ++s) {
@@ -267,8 +329,11 @@ __global__ __launch_bounds__(256, 2) void ctrgc_agg_bwd_kernel(int N, int Cout, 
                 if (t < T) {
 #pragma unroll
                     for (int v = 0; v < VW; ++v) {
-                        orow[(long long)t * V + (vb + v) * 16 + j] = acc[s][v][r];
-                        sb[s] += acc[s][v][r];
+                        const int vv = (vb + v) * 16 + j;
+                        if (VP == V || vv < V) {
+                            orow[(long long)t * V + vv] = acc[s][v][r];
+                            sb[s] += acc[s][v][r];
+                        }
                     }
                 }
             }
@@ -291,9 +356,10 @@ __global__ __launch_bounds__(256, 2) void ctrgc_agg_bwd_kernel(int N, int Cout, 
 template <int V, int ST>
 __global__ __launch_bounds__(256) void ctrgc_de_acc_mfma_kernel(int N, int Cout, int T, const float* __restrict__ x3, const SrcDev dy,
                                                                 float* __restrict__ dE) {
-    constexpr int P = V + 16, NUT = V / 16, UW = NUT < 4 ? NUT : 4, VWAVES = 4 / UW, VPW = NUT / VWAVES, BT = TL_BT;
-    constexpr int NPX = ST * BT * V / 4 / 256, NPY = BT * V / 4 / 256, VV = V * V;
-    static_assert(V % 32 == 0 && (BT * V / 4) % 256 == 0, "tile geometry");
+    using G = TlGeo<V>;
+    constexpr int VP = G::VP, P = VP + 16, NUT = G::NUT, UW = NUT < 4 ? NUT : 4, VWAVES = 4 / UW, VPW = NUT / VWAVES, BT = TL_BT;
+    constexpr int CH4 = BT * V / 4, NPX = (ST * CH4 + 255) / 256, NPY = (CH4 + 255) / 256, VV = V * V;
+    static_assert((BT * V) % 4 == 0, "tile geometry");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Zs = smem;                         // [BT][P]      dy chunk (prologue applied)
     float* Xs = Zs + BT * P;                  // [ST][BT][P]
@@ -306,19 +372,21 @@ __global__ __launch_bounds__(256) void ctrgc_de_acc_mfma_kernel(int N, int Cout,
     const float c2 = (dy.coef && dy.x2) ? dy.coef[dy.ctot + ch] : 0.f;
     const float c0 = dy.coef ? dy.coef[2 * dy.ctot + ch] : 0.f;
     const long long dyb = ((long long)n * dy.ctot + ch) * TV;
+    if constexpr (VP != V) for (int e = tid; e < (ST + 1) * BT * P; e += 256) smem[e] = 0.f;   // joint pads stay zero
 
     float4 px[NPX], p1[NPY], p2[NPY];
     auto prefetch = [&](int t0) {
 #pragma unroll
         for (int i = 0; i < NPX; ++i) {
-            const int e = tid + i * 256, s = e / (BT * V / 4), r = e - s * (BT * V / 4);
-            px[i] = t0 + (r * 4) / V < T ? reinterpret_cast<const float4*>(x3 + (((long long)n * ST + s) * Cout + c) * TV + (long long)t0 * V)[r]
-                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int e = tid + i * 256, ec = e < ST * CH4 ? e : 0, s = ec / CH4, r = ec - s * CH4;
+            const bool ok = e < ST * CH4 && t0 + (r * 4) / V < T;
+            px[i] = ok ? reinterpret_cast<const float4*>(x3 + (((long long)n * ST + s) * Cout + c) * TV + (long long)t0 * V)[r]
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int i = 0; i < NPY; ++i) {
             const int r = tid + i * 256;
-            const bool ok = t0 + (r * 4) / V < T;
+            const bool ok = r < CH4 && t0 + (r * 4) / V < T;
             p1[i] = ok ? reinterpret_cast<const float4*>(dy.x1 + dyb + (long long)t0 * V)[r] : make_float4(0.f, 0.f, 0.f, 0.f);
             p2[i] = (ok && dy.x2) ? reinterpret_cast<const float4*>(dy.x2 + dyb + (long long)t0 * V)[r] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -331,22 +399,29 @@ __global__ __launch_bounds__(256) void ctrgc_de_acc_mfma_kernel(int N, int Cout,
         for (int v = 0; v < VPW; ++v) acc[s][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int t0 = 0; t0 < T; t0 += BT) {
         __syncthreads();
+        const int valid = min(BT, T - t0) * V;
 #pragma unroll
         for (int i = 0; i < NPX; ++i) {
-            const int e = tid + i * 256, s = e / (BT * V / 4), r = e - s * (BT * V / 4);
-            const int tl = (r * 4) / V, v = (r * 4) - tl * V;
-            *reinterpret_cast<float4*>(Xs + (s * BT + tl) * P + v) = px[i];
+            const int e = tid + i * 256, s = e / CH4, r = e - s * CH4;
+            if (e < ST * CH4) {
+                float4 t = px[i];
+                if (r * 4 + 3 >= valid) { if (r * 4 + 0 >= valid) t.x = 0.f; if (r * 4 + 1 >= valid) t.y = 0.f; if (r * 4 + 2 >= valid) t.z = 0.f; t.w = 0.f; }
+                if constexpr (G::AL) { const int tl = (r * 4) / V, v = (r * 4) - tl * V; *reinterpret_cast<float4*>(Xs + (s * BT + tl) * P + v) = t; }
+                else scatter4<V>(Xs + s * BT * P, P, r * 4, t);
+            }
         }
 #pragma unroll
         for (int i = 0; i < NPY; ++i) {
             const int r = tid + i * 256;
-            const int tl = (r * 4) / V, u = (r * 4) - tl * V;
-            const bool ok = t0 + tl < T;
-            float4 o = make_float4(fmaf(c1, p1[i].x, fmaf(c2, p2[i].x, c0)), fmaf(c1, p1[i].y, fmaf(c2, p2[i].y, c0)),
-                                   fmaf(c1, p1[i].z, fmaf(c2, p2[i].z, c0)), fmaf(c1, p1[i].w, fmaf(c2, p2[i].w, c0)));
-            if (dy.act == 1) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-            if (!ok) o = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(Zs + tl * P + u) = o;
+            if (r < CH4) {
+                float o[4] = {fmaf(c1, p1[i].x, fmaf(c2, p2[i].x, c0)), fmaf(c1, p1[i].y, fmaf(c2, p2[i].y, c0)),
+                              fmaf(c1, p1[i].z, fmaf(c2, p2[i].z, c0)), fmaf(c1, p1[i].w, fmaf(c2, p2[i].w, c0))};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { if (dy.act == 1) o[k] = fmaxf(o[k], 0.f); if (r * 4 + k >= valid) o[k] = 0.f; }
+                const float4 t = make_float4(o[0], o[1], o[2], o[3]);
+                if constexpr (G::AL) { const int tl = (r * 4) / V, u = (r * 4) - tl * V; *reinterpret_cast<float4*>(Zs + tl * P + u) = t; }
+                else scatter4<V>(Zs, P, r * 4, t);
+            }
         }
         __syncthreads();
         if (t0 + BT < T) prefetch(t0 + BT);
@@ -366,7 +441,10 @@ __global__ __launch_bounds__(256) void ctrgc_de_acc_mfma_kernel(int N, int Cout,
 #pragma unroll
         for (int v = 0; v < VPW; ++v)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[(ut * 16 + kq * 4 + r) * V + (vb + v) * 16 + j] = acc[s][v][r];
+            for (int r = 0; r < 4; ++r) {
+                const int uu = ut * 16 + kq * 4 + r, vv = (vb + v) * 16 + j;
+                if (VP == V || (uu < V && vv < V)) o[uu * V + vv] = acc[s][v][r];
+            }
     }
 }
 
@@ -553,16 +631,21 @@ __global__ __launch_bounds__(512) void ctrgc_de_tail_tiled_kernel(const TTArgs a
 }
 
 template <int V>
-constexpr size_t agg_lds(int ST, bool bwd) { return sizeof(float) * (size_t)(ST * V * (V + 2) + (bwd ? 1 : ST) * TL_BT * (V + 2)); }
+constexpr size_t agg_lds(int ST, bool bwd) {
+    return sizeof(float) * (size_t)(ST * TlGeo<V>::VP * TlGeo<V>::PE + (bwd ? 1 : ST) * TL_BT * TlGeo<V>::PE);
+}
 
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
 // host
 // ---------------------------------------------------------------------------------------------------------------
-static bool tiled_v_ok(int V) { return V == 64 || V == 32; }
+static bool tiled_v_ok(int V) { return V == 64 || V == 32; }          // the whole family (E / tail tiles included)
+static bool stream_v_ok(int V) { return V == 64 || V == 32 || V == 25 || V == 20; }   // the three streaming kernels
 
-extern "C" int tamgcn_ctrgc_tiled_supported(int V) { return tiled_v_ok(V) ? 1 : 0; }
+// 1: the whole tiled family; 2: only the streaming kernels (aggregation fwd / bwd, dE accumulation): E and the dE tail
+// then come from the LDS-resident family's tamgcn_ctrgc_build_e / tamgcn_ctrgc_bwd_de_tail; 0: neither
+extern "C" int tamgcn_ctrgc_tiled_supported(int V) { return tiled_v_ok(V) ? 1 : (stream_v_ok(V) ? 2 : 0); }
 
 // largest dynamic-LDS request of the tiled family for (S, V, R): what tamgcn_ctrgc_lds_bytes reports for these V
 int tamgcn_ctrgc_tiled_lds_bytes(int S, int V, int R) {
@@ -610,7 +693,7 @@ extern "C" int tamgcn_ctrgc_tiled_build_e(const tamgcn_ctrgc_desc* d, float* E, 
 
 static int tiled_common_check(const tamgcn_ctrgc_desc* d, const char* who) {
     if (!d) { tamgcn_set_error("%s: null descriptor", who); return -1; }
-    if (!tiled_v_ok(d->V)) { tamgcn_set_error("%s: V=%d (the tiled CTRGC kernels are built for V in {32, 64})", who, d->V); return -1; }
+    if (!stream_v_ok(d->V)) { tamgcn_set_error("%s: V=%d (the streaming CTRGC kernels are built for V in {20, 25, 32, 64})", who, d->V); return -1; }
     if (!(d->S == 1 || d->S == 3)) { tamgcn_set_error("%s: S=%d (1 or 3 subsets)", who, d->S); return -1; }
     if (!(d->N > 0 && d->Cout > 0 && d->T > 0)) { tamgcn_set_error("%s: bad dims N=%d Cout=%d T=%d", who, d->N, d->Cout, d->T); return -1; }
     if ((long long)d->N * d->Cout >= (1LL << 31)) { tamgcn_set_error("%s: N*Cout too large for the grid", who); return -1; }
@@ -625,6 +708,10 @@ extern "C" int tamgcn_ctrgc_tiled_agg_fwd(const tamgcn_ctrgc_desc* d, const floa
     else TL_CASE(ctrgc_agg_fwd_kernel, 64, 1, agg_lds<64>(1, false), d->N, d->Cout, d->T, x3, E, y, stats_part)
     else TL_CASE(ctrgc_agg_fwd_kernel, 32, 3, agg_lds<32>(3, false), d->N, d->Cout, d->T, x3, E, y, stats_part)
     else TL_CASE(ctrgc_agg_fwd_kernel, 32, 1, agg_lds<32>(1, false), d->N, d->Cout, d->T, x3, E, y, stats_part)
+    else TL_CASE(ctrgc_agg_fwd_kernel, 25, 3, agg_lds<25>(3, false), d->N, d->Cout, d->T, x3, E, y, stats_part)
+    else TL_CASE(ctrgc_agg_fwd_kernel, 25, 1, agg_lds<25>(1, false), d->N, d->Cout, d->T, x3, E, y, stats_part)
+    else TL_CASE(ctrgc_agg_fwd_kernel, 20, 3, agg_lds<20>(3, false), d->N, d->Cout, d->T, x3, E, y, stats_part)
+    else TL_CASE(ctrgc_agg_fwd_kernel, 20, 1, agg_lds<20>(1, false), d->N, d->Cout, d->T, x3, E, y, stats_part)
     TG_CHECK(launched, "tamgcn_ctrgc_tiled_agg_fwd: no instantiation for S=%d V=%d", d->S, d->V);
     TG_LAUNCH_CHECK("tamgcn_ctrgc_tiled_agg_fwd");
     return 0;
@@ -640,6 +727,10 @@ extern "C" int tamgcn_ctrgc_tiled_agg_bwd(const tamgcn_ctrgc_desc* d, const tamg
     else TL_CASE(ctrgc_agg_bwd_kernel, 64, 1, agg_lds<64>(1, true), d->N, d->Cout, d->T, dys, E, dx3, db3_part)
     else TL_CASE(ctrgc_agg_bwd_kernel, 32, 3, agg_lds<32>(3, true), d->N, d->Cout, d->T, dys, E, dx3, db3_part)
     else TL_CASE(ctrgc_agg_bwd_kernel, 32, 1, agg_lds<32>(1, true), d->N, d->Cout, d->T, dys, E, dx3, db3_part)
+    else TL_CASE(ctrgc_agg_bwd_kernel, 25, 3, agg_lds<25>(3, true), d->N, d->Cout, d->T, dys, E, dx3, db3_part)
+    else TL_CASE(ctrgc_agg_bwd_kernel, 25, 1, agg_lds<25>(1, true), d->N, d->Cout, d->T, dys, E, dx3, db3_part)
+    else TL_CASE(ctrgc_agg_bwd_kernel, 20, 3, agg_lds<20>(3, true), d->N, d->Cout, d->T, dys, E, dx3, db3_part)
+    else TL_CASE(ctrgc_agg_bwd_kernel, 20, 1, agg_lds<20>(1, true), d->N, d->Cout, d->T, dys, E, dx3, db3_part)
     TG_CHECK(launched, "tamgcn_ctrgc_tiled_agg_bwd: no instantiation for S=%d V=%d", d->S, d->V);
     TG_LAUNCH_CHECK("tamgcn_ctrgc_tiled_agg_bwd");
     return 0;
@@ -651,11 +742,15 @@ extern "C" int tamgcn_ctrgc_tiled_de_acc(const tamgcn_ctrgc_desc* d, const tamgc
     TG_CHECK(dy->ctot >= dy->coff + d->Cout, "tamgcn_ctrgc_tiled_de_acc: dy has %d channels from %d, need %d", dy->ctot, dy->coff, d->Cout);
     const SrcDev dys = make_src(*dy);
     bool launched = false;
-#define TL_DE_LDS(VV_, SS_) (sizeof(float) * (size_t)((SS_ + 1) * TL_BT * (VV_ + 16)))
+#define TL_DE_LDS(VV_, SS_) (sizeof(float) * (size_t)((SS_ + 1) * TL_BT * (TlGeo<VV_>::VP + 16)))
     TL_CASE(ctrgc_de_acc_mfma_kernel, 64, 3, TL_DE_LDS(64, 3), d->N, d->Cout, d->T, x3, dys, dE)
     else TL_CASE(ctrgc_de_acc_mfma_kernel, 64, 1, TL_DE_LDS(64, 1), d->N, d->Cout, d->T, x3, dys, dE)
     else TL_CASE(ctrgc_de_acc_mfma_kernel, 32, 3, TL_DE_LDS(32, 3), d->N, d->Cout, d->T, x3, dys, dE)
     else TL_CASE(ctrgc_de_acc_mfma_kernel, 32, 1, TL_DE_LDS(32, 1), d->N, d->Cout, d->T, x3, dys, dE)
+    else TL_CASE(ctrgc_de_acc_mfma_kernel, 25, 3, TL_DE_LDS(25, 3), d->N, d->Cout, d->T, x3, dys, dE)
+    else TL_CASE(ctrgc_de_acc_mfma_kernel, 25, 1, TL_DE_LDS(25, 1), d->N, d->Cout, d->T, x3, dys, dE)
+    else TL_CASE(ctrgc_de_acc_mfma_kernel, 20, 3, TL_DE_LDS(20, 3), d->N, d->Cout, d->T, x3, dys, dE)
+    else TL_CASE(ctrgc_de_acc_mfma_kernel, 20, 1, TL_DE_LDS(20, 1), d->N, d->Cout, d->T, x3, dys, dE)
     TG_CHECK(launched, "tamgcn_ctrgc_tiled_de_acc: no instantiation for S=%d V=%d", d->S, d->V);
     TG_LAUNCH_CHECK("tamgcn_ctrgc_tiled_de_acc");
     return 0;

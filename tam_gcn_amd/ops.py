@@ -302,9 +302,27 @@ def _ctrgc_desc(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, E=None):
     return d
 
 
+# V = 20 on the unfused MFMA route as an experiment (the fused LDS-resident kernels are the default there)
+STREAM_V20 = os.environ.get('TAMGCN_CTRGC_MFMA', '0') == '1'
+
+
+def ctrgc_route(V):
+    """'fused'  V = 20 (25 if the streaming kernels are disabled): LDS-resident E tiles, x3 GEMM + VALU aggregation in one kernel;
+    'stream' V = 25: x3 = W3 x through the pointwise GEMM (kept in HBM), aggregation / dE accumulation on MFMA with the joints padded
+             to 32 in LDS, E and the dE tail from the LDS-resident family (2.5x the fused V = 25 geometry, which fits only 4
+             frames per chunk beside its 120 KB of E tiles);
+    'tiled'  V in {32, 64}: the same with tiled E / tail kernels (E of one channel is 48 KB at V = 64)."""
+    k = _lib_().tamgcn_ctrgc_tiled_supported(int(V))
+    if k == 1:
+        return 'tiled'
+    if k == 2 and (V != 20 or STREAM_V20) and os.environ.get('TAMGCN_CTRGC_STREAM', '1') != '0':
+        return 'stream'
+    return 'fused'
+
+
 def ctrgc_tiled(V):
-    """True for the large-skeleton geometry (V in {32, 64}): x3 through the pointwise GEMM, aggregation on MFMA."""
-    return bool(_lib_().tamgcn_ctrgc_tiled_supported(int(V)))
+    """True when CTRGC runs as x3 GEMM + MFMA aggregation kernels (routes 'tiled' and 'stream')."""
+    return ctrgc_route(V) != 'fused'
 
 
 def ctrgc_build_E(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R):
@@ -312,7 +330,7 @@ def ctrgc_build_E(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R):
     N, _, T, V = x.x1.shape
     d = _ctrgc_desc(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R)
     E = empty(N, S, Cout, V, V, like=x.x1)
-    if ctrgc_tiled(V):
+    if ctrgc_route(V) == 'tiled':
         _lib.check(_lib_().tamgcn_ctrgc_tiled_build_e(C.byref(d), _ptr(E), _stream()), 'tamgcn_ctrgc_tiled_build_e')
     else:
         _lib.check(_lib_().tamgcn_ctrgc_build_e(C.byref(d), _ptr(E), _stream()), 'tamgcn_ctrgc_build_e')
@@ -383,10 +401,11 @@ def ctrgc_bwd_de(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy, x3=None, 
     d = _ctrgc_desc(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R)
     dyc = dy.c()
     like = x.x1
-    if ctrgc_tiled(V):
+    route = ctrgc_route(V)
+    dE = None
+    if route != 'fused':
         if x3 is None:
             x3 = _x3_gemm(x, w3, b3, Cin, Cout, S)
-        NUC = _lib_().tamgcn_ctrgc_tiled_chunks(V)
         dE = empty(N, S, Cout, V, V, like=like)
         for n0, n1 in n_chunks(N, S * Cout * T * V):
             d.N = n1 - n0
@@ -394,6 +413,8 @@ def ctrgc_bwd_de(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy, x3=None, 
             _lib.check(_lib_().tamgcn_ctrgc_tiled_de_acc(C.byref(d), C.byref(dyc), _ptr(x3[n0:n1]), _ptr(dE[n0:n1]), _stream()),
                        'tamgcn_ctrgc_tiled_de_acc')
         d.N = N
+    if route == 'tiled':
+        NUC = _lib_().tamgcn_ctrgc_tiled_chunks(V)
         dA_part = empty(N, S, V, V, like=like)
         dw4_part = empty(N * NUC, S, Cout, R, like=like)
         db4_part = empty(N * NUC, S, Cout, like=like)
@@ -405,10 +426,13 @@ def ctrgc_bwd_de(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy, x3=None, 
         return (reduce_sum(dA_part, N), reduce_sum(dw4_part, N * NUC, chunks=[(Cout, R, 1, 1)] * S if ps else None),
                 reduce_sum(db4_part, N * NUC, chunks=[(Cout,)] * S if ps else None), reduce_sum(dal_part, N * S * NUC),
                 reduce_sum(dpq, NUC, immediate=True))
-    if x3 is not None and R <= 32:
-        dE = empty(N, S, Cout, V, V, like=like)
-        _lib.check(_lib_().tamgcn_ctrgc_bwd_de_acc(C.byref(d), C.byref(dyc), _ptr(x3), _ptr(dE), _stream()),
-                   'tamgcn_ctrgc_bwd_de_acc')
+    if route == 'stream' and R > 32:
+        raise RuntimeError('tam_gcn_amd: CTRGC with R > 32 rel-channels is not built for V = %d' % V)
+    if (x3 is not None or dE is not None) and R <= 32:
+        if dE is None:
+            dE = empty(N, S, Cout, V, V, like=like)
+            _lib.check(_lib_().tamgcn_ctrgc_bwd_de_acc(C.byref(d), C.byref(dyc), _ptr(x3), _ptr(dE), _stream()),
+                       'tamgcn_ctrgc_bwd_de_acc')
         G = 1                                           # channel groups per (n, subset); the per-workgroup fixed cost (D fill,
         #                                               dp/dq sums) equals ~1.4 channel chunks, so splitting did not pay (measured)
         while Cout % (16 * G):

@@ -66,7 +66,7 @@ def test_abi_rejects_bad_arguments_without_touching_the_gpu():
     assert lib.tamgcn_ctrgc_lds_bytes(3, 20, 8) > 64 * 1024          # N-UCLA tiles: LDS resident
     assert lib.tamgcn_ctrgc_lds_bytes(3, 25, 8) > 0                  # NTU
     assert lib.tamgcn_ctrgc_lds_bytes(3, 64, 32) > 0                 # V = 64: tiled family
-    assert lib.tamgcn_ctrgc_tiled_supported(64) == 1 and lib.tamgcn_ctrgc_tiled_supported(20) == 0
+    assert lib.tamgcn_ctrgc_tiled_supported(64) == 1 and lib.tamgcn_ctrgc_tiled_supported(25) == 2 and lib.tamgcn_ctrgc_tiled_supported(40) == 0
     assert lib.tamgcn_ctrgc_lds_bytes(3, 40, 8) == -1                # neither family
     assert lib.tamgcn_ctrgc_lds_bytes(2, 20, 8) == -1                # subsets: 1 or 3
     # a descriptor with impossible sizes is refused with its own message

@@ -295,3 +295,45 @@ def test_full_size_properties():
     g2 = m.l10.tcn1.branches[0][3].conv.weight.grad
     assert (outp - out[perm]).abs().max() <= 2e-4 * out.abs().max()
     assert (g1 - g2).norm() <= 2e-3 * g1.norm()
+
+
+def test_ntu_full_size_properties():
+    """BASELINE configs[3] at its stated size: NTU-RGB+D graph, 25 joints x 300 frames x 2 persons, batch 128 (N*M = 256 skeleton
+    sequences, 56 GiB of saved activations).  No oracle run is affordable at this size, so the domain's properties: (1) eval mode: a
+    clip's logits do not depend on the batch it sits in (128-clip launch vs a 2-clip launch: every tile path, the clip-chunked
+    launches, the V = 25 line buffers with their 28-float frame pitch); (2) train mode: permuting the batch permutes the logits and
+    leaves a summed-loss parameter gradient unchanged."""
+    dev = torch.device('cuda:0')
+    margs = dict(num_class=60, num_point=25, num_person=2, graph='graph.ntu_rgb_d.Graph', graph_args=dict(labeling_mode='spatial'))
+    m = M.Model(**margs)
+    fill_state_(m.state_dict(), seed=MODEL_PARAM_SEED)
+    m = m.to(dev)
+    g = torch.Generator().manual_seed(12)
+    B = 128
+    x = (torch.rand(B, 3, 300, 25, 2, generator=g) * 2 - 1).to(dev)
+    lab = torch.randint(0, 60, (B,), generator=g).to(dev)
+    m.train()
+    for mod in m.modules():
+        if isinstance(mod, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            mod.momentum = 1.0                            # running statistics := this batch's
+    with torch.no_grad():
+        m(x)
+    m.eval()
+    with torch.no_grad():
+        full = m(x)
+        sub = m(x[60:62].contiguous())
+    assert torch.isfinite(full).all()
+    assert (full[60:62] - sub).abs().max() <= 1e-4 * full.abs().max()
+    m.train()
+    perm = torch.randperm(B, generator=g).to(dev)
+    out = m(x)
+    torch.nn.functional.cross_entropy(out, lab, reduction='sum').backward()
+    g1 = m.l10.tcn1.branches[0][3].conv.weight.grad.clone()
+    g1b = m.l2.gcn1.convs[1].conv3.weight.grad.clone()
+    for p in m.parameters():
+        p.grad = None
+    outp = m(x[perm].contiguous())
+    torch.nn.functional.cross_entropy(outp, lab[perm], reduction='sum').backward()
+    assert (outp - out[perm]).abs().max() <= 2e-4 * out.abs().max()
+    assert (g1 - m.l10.tcn1.branches[0][3].conv.weight.grad).norm() <= 2e-3 * g1.norm()
+    assert (g1b - m.l2.gcn1.convs[1].conv3.weight.grad).norm() <= 5e-3 * g1b.norm()
