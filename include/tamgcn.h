@@ -111,6 +111,12 @@ typedef struct tamgcn_conv_desc {
     int auxctot, auxcoff;
     float* stats_part;              /* optional [2][stats_ctot][nparts] written at channel stats_coff+m */
     int stats_ctot, stats_coff;
+    /* eval-mode fusion: with BatchNorm folded to a per-channel affine the convolution can finish
+     * its consumer's work:  y = act( c1[ch]*(conv + bias) + c0[ch] + bcast + add1 + add2 ),  ch = ycoff + m,
+     * c1 = post_coef[ch], c0 = post_coef[2*post_ctot + ch] (the [3][post_ctot] layout tamgcn_bn_fwd_finalize writes),
+     * post_act 1 = ReLU after the adds.  NULL / 0: the plain form above. */
+    const float* post_coef;
+    int post_ctot, post_act;
 } tamgcn_conv_desc;
 
 /* number of stats partials per channel the call writes (= N * t-tiles) */
@@ -281,6 +287,10 @@ int tamgcn_gcn_mid_bwd(const float* dsum, const float* ddiff, const float* y_pre
  * written at channel ycoff of y (N, yctot, T_out, V) + (sum, sum^2) partials [2][yctot][nparts]. */
 int tamgcn_maxpool_fwd(const tamgcn_src* src, int N, int C, int T_in, int V, int stride,
                        float* y, int yctot, int ycoff, int T_out, float* stats_part, void* stream);
+/* the same pooled value finished for an eval-mode block (row f2):  y = act( c1[ch]*maxpool + c0[ch] + add ),
+ * ch = ycoff + c, coef [3][yctot] as tamgcn_bn_fwd_finalize writes it, add optional with the geometry of y. */
+int tamgcn_maxpool_post_fwd(const tamgcn_src* src, int N, int C, int T_in, int V, int stride,
+                            float* y, int yctot, int ycoff, int T_out, const float* coef, const float* add, int relu, void* stream);
 /* d src_value routed to the first arg-max of each window, times relu mask (value > 0);
  * gy goes through its own prologue; result written at channel dcoff of d (N, dctot, T_in, V),
  * partials (sum d, sum d*src.x1) at the same channel of [2][dctot][nparts]. */

@@ -28,7 +28,8 @@ class ConvDesc(C.Structure):
                 ('add1', C.c_void_p), ('add2', C.c_void_p), ('bcast', C.c_void_p), ('bcast_scale', C.c_float),
                 ('mask', C.POINTER(Src)),
                 ('aux', C.c_void_p), ('aux_center', C.c_void_p), ('auxctot', C.c_int), ('auxcoff', C.c_int),
-                ('stats_part', C.c_void_p), ('stats_ctot', C.c_int), ('stats_coff', C.c_int)]
+                ('stats_part', C.c_void_p), ('stats_ctot', C.c_int), ('stats_coff', C.c_int),
+                ('post_coef', C.c_void_p), ('post_ctot', C.c_int), ('post_act', C.c_int)]
 
 
 class WgradDesc(C.Structure):
@@ -94,6 +95,7 @@ SIGNATURES = {
     'tamgcn_gcn_tail_bwd': (_i, [_p, _p, _SP, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
     'tamgcn_gcn_mid_bwd': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
     'tamgcn_maxpool_fwd': (_i, [_SP, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _p]),
+    'tamgcn_maxpool_post_fwd': (_i, [_SP, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _p, _i, _p]),
     'tamgcn_maxpool_bwd': (_i, [_SP, _SP, _p, _i, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p]),
     'tamgcn_add_act_fwd': (_i, [_SP, _SP, _i, _i, _i, _i, _i, _p, _p]),
     'tamgcn_add_act_bwd': (_i, [_p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),

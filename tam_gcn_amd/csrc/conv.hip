@@ -37,6 +37,7 @@ struct ConvArgs {
     SrcDev mask; int has_mask;
     const float* aux; const float* aux_center; int auxctot, auxcoff;
     float* stats_part; int stats_ctot, stats_coff, nparts;
+    const float* post_coef; int post_ctot, post_act;   // eval-mode output affine (folded BatchNorm) + ReLU after the residual adds
     // tiling (host chosen)
     int BT;        // output frames per block
     int CW;        // column tiles per wave
@@ -78,10 +79,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[4]
                 if (m >= a.M) continue;
                 float val = acc[mt][c][r];
                 if (a.bias) val += a.bias[m];
+                if (a.post_coef) val = fmaf(a.post_coef[a.ycoff + m], val, a.post_coef[2 * a.post_ctot + a.ycoff + m]);
                 long long idx = (((long long)n * a.yctot + a.ycoff + m) * a.T_y + t) * V + vv[c];
                 if (a.bcast) val = fmaf(a.bcast[((long long)m * a.N + n) * V + vv[c]], a.bcast_scale, val);
                 if (a.add1) val += a.add1[idx];
                 if (a.add2) val += a.add2[idx];
+                if (a.post_act == 1) val = fmaxf(val, 0.f);
                 if (a.has_mask) {
                     int mch = a.mask.coff + m;
                     long long midx = (((long long)n * a.mask.ctot + mch) * a.T_y + t) * V + vv[c];
@@ -263,6 +266,8 @@ __device__ __forceinline__ void staged_rows(const ConvArgs& a, const float* Tt, 
     if (rowok) {
         const float bia = a.bias ? a.bias[m] : 0.f;
         const float ctr = a.aux ? a.aux_center[a.auxcoff + m] : 0.f;
+        const float pc1 = a.post_coef ? a.post_coef[a.ycoff + m] : 1.f, pc0 = a.post_coef ? a.post_coef[2 * a.post_ctot + a.ycoff + m] : 0.f;
+        const float plo = a.post_act == 1 ? 0.f : -__builtin_inff();
         const long long ybase = ((long long)n * a.yctot + a.ycoff + m) * a.T_y * V;
         const long long mbase = a.has_mask ? ((long long)n * a.mask.ctot + a.mask.coff + m) * a.T_y * V : 0;
         const long long abase = a.aux ? ((long long)n * a.auxctot + a.auxcoff + m) * a.T_y * V : 0;
@@ -280,7 +285,8 @@ __device__ __forceinline__ void staged_rows(const ConvArgs& a, const float* Tt, 
             if (vecok && col + 4 <= ncols) {
                 const long long off = (long long)(t0 + fr) * a.ostride * V + v0 + v;
                 float4 val = *reinterpret_cast<const float4*>(Tt + row * PT + col);
-                val.x += bia; val.y += bia; val.z += bia; val.w += bia;
+                val.x = fmaf(pc1, val.x + bia, pc0); val.y = fmaf(pc1, val.y + bia, pc0);
+                val.z = fmaf(pc1, val.z + bia, pc0); val.w = fmaf(pc1, val.w + bia, pc0);
                 if (bc) {
                     float4 b;
                     if ((V & 3) == 0) b = *reinterpret_cast<const float4*>(bc + v0 + v);
@@ -290,6 +296,7 @@ __device__ __forceinline__ void staged_rows(const ConvArgs& a, const float* Tt, 
                 }
                 if (a.add1) { float4 t = *reinterpret_cast<const float4*>(a.add1 + ybase + off); val.x += t.x; val.y += t.y; val.z += t.z; val.w += t.w; }
                 if (a.add2) { float4 t = *reinterpret_cast<const float4*>(a.add2 + ybase + off); val.x += t.x; val.y += t.y; val.z += t.z; val.w += t.w; }
+                val.x = fmaxf(val.x, plo); val.y = fmaxf(val.y, plo); val.z = fmaxf(val.z, plo); val.w = fmaxf(val.w, plo);
                 if (a.has_mask) {
                     float4 q = *reinterpret_cast<const float4*>(a.mask.x1 + mbase + off);
                     float4 q2 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -315,10 +322,11 @@ __device__ __forceinline__ void staged_rows(const ConvArgs& a, const float* Tt, 
                 for (int i = 0; i < 4 && col + i < ncols; ++i) {
                     const int ci = col + i, fi = ci / Vs, vi = ci - fi * Vs;
                     const long long off = (long long)(t0 + fi) * a.ostride * V + v0 + vi;
-                    float val = Tt[row * PT + ci] + bia;
+                    float val = fmaf(pc1, Tt[row * PT + ci] + bia, pc0);
                     if (bc) val = fmaf(bc[(v0 + vi) % V], a.bcast_scale, val);
                     if (a.add1) val += a.add1[ybase + off];
                     if (a.add2) val += a.add2[ybase + off];
+                    val = fmaxf(val, plo);
                     if (a.has_mask) {
                         const float q = a.mask.x1[mbase + off], q2 = a.mask.x2 ? a.mask.x2[mbase + off] : 0.f;
                         if (!(fmaf(mc1, q, fmaf(mc2, q2, mc0)) > 0.f)) val = 0.f;
@@ -1093,6 +1101,8 @@ extern "C" int tamgcn_conv(const tamgcn_conv_desc* d, void* stream) {
     a.aux = d->aux; a.aux_center = d->aux_center; a.auxctot = d->auxctot; a.auxcoff = d->auxcoff;
     TG_CHECK(!d->aux || d->aux_center, "tamgcn_conv: aux needs aux_center");
     a.stats_part = d->stats_part; a.stats_ctot = d->stats_ctot; a.stats_coff = d->stats_coff;
+    a.post_coef = d->post_coef; a.post_ctot = d->post_ctot; a.post_act = d->post_act;
+    TG_CHECK(!d->post_coef || d->post_ctot >= d->ycoff + d->M, "tamgcn_conv: post_coef has %d channels, need %d", d->post_ctot, d->ycoff + d->M);
     a.nparts = d->N * p.ntt * p.nsl;
     a.BT = p.BT; a.CW = p.CW; a.TIN = p.TIN; a.lstride = p.lstride; a.sB = p.sB; a.LB = p.LB; a.pitchB = p.pitchB;
     a.Vs = p.Vs; a.Vp = p.Vp; a.nsl = p.nsl;

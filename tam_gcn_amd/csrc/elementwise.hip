@@ -190,6 +190,27 @@ __global__ __launch_bounds__(EW_THREADS) void maxpool_fwd_kernel(RowGeo geo, Src
     if (part) row_store_sums(s, 2, part, yctot, N, ycoff + c, n, geo, li, rowok);
 }
 
+__global__ __launch_bounds__(EW_THREADS) void maxpool_post_fwd_kernel(RowGeo geo, SrcDev src, int C, int T_in, int V, int stride,
+                                                                      float* y, int yctot, int ycoff, int T_out, const float* coef, const float* add, int relu) {
+    int c, n, li;
+    const bool rowok = row_coords(geo, C, c, n, li);
+    if (!rowok) return;
+    const long long bs = ((long long)n * src.ctot + src.coff + c) * T_in * V;
+    const long long yb = ((long long)n * yctot + ycoff + c) * T_out * V;
+    const float c1 = coef[ycoff + c], c0 = coef[2 * yctot + ycoff + c];
+    for (int i = li; i < T_out * V; i += geo.tpr) {
+        int t = i / V, v = i - t * V;
+        float best = -INFINITY;
+        for (int k = -1; k <= 1; ++k) {
+            int th = t * stride + k;
+            if (th >= 0 && th < T_in) best = fmaxf(best, src_value(src, bs + (long long)th * V + v, src.coff + c));
+        }
+        float o = fmaf(c1, best, c0);
+        if (add) o += add[yb + i];
+        y[yb + i] = relu ? fmaxf(o, 0.f) : o;
+    }
+}
+
 // The window logic needs up to nine neighbouring activations per element; read straight from memory that is a
 // chain of dependent L2 round trips inside data-dependent control flow (3400 cycles per element measured).  With
 // LDS = 1 the row's activations (prologue applied) and its upstream gradients are staged in LDS first -- one
@@ -394,6 +415,18 @@ extern "C" int tamgcn_maxpool_fwd(const tamgcn_src* src, int N, int C, int T_in,
                        geo, make_src(*src), C, T_in, V, stride, y, yctot, ycoff, T_out, N, stats_part);
     tamgcn_note_kernel("maxpool_fwd_kernel");
     TG_LAUNCH_CHECK("tamgcn_maxpool_fwd");
+    return 0;
+}
+
+extern "C" int tamgcn_maxpool_post_fwd(const tamgcn_src* src, int N, int C, int T_in, int V, int stride,
+                                       float* y, int yctot, int ycoff, int T_out, const float* coef, const float* add, int relu, void* stream) {
+    TG_CHECK(src && src->x1 && y && coef && grid_ok(N, C) && stride >= 1, "tamgcn_maxpool_post_fwd: bad args");
+    TG_CHECK(T_out == (T_in + 2 - 3) / stride + 1, "tamgcn_maxpool_post_fwd: T_out=%d inconsistent with T_in=%d stride=%d", T_out, T_in, stride);
+    const RowGeo geo = row_geo(N, C, T_out * V, false);
+    hipLaunchKernelGGL(maxpool_post_fwd_kernel, row_grid(geo), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       geo, make_src(*src), C, T_in, V, stride, y, yctot, ycoff, T_out, coef, add, relu);
+    tamgcn_note_kernel("maxpool_post_fwd_kernel");
+    TG_LAUNCH_CHECK("tamgcn_maxpool_post_fwd");
     return 0;
 }
 

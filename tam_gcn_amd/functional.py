@@ -92,15 +92,21 @@ class Fork:
 
 class BN:
     """Borrowed view of one nn.BatchNorm{1,2}d's tensors."""
-    __slots__ = ('w', 'b', 'rm', 'rv', 'nbt', 'mom', 'eps', 'C')
+    __slots__ = ('w', 'b', 'rm', 'rv', 'nbt', 'mom', 'eps', 'C', 'm')
 
     def __init__(self, m):
         if m.momentum is None or not m.track_running_stats or not m.affine:
             raise RuntimeError('tam_gcn_amd: BatchNorm must be affine with running stats and a fixed momentum')
         self.w, self.b, self.rm, self.rv, self.nbt = m.weight, m.bias, m.running_mean, m.running_var, m.num_batches_tracked
-        self.mom, self.eps, self.C = float(m.momentum), float(m.eps), m.num_features
+        self.mom, self.eps, self.C, self.m = float(m.momentum), float(m.eps), m.num_features, m
+
+    def tensors(self):
+        return (self.w, self.b, self.rm, self.rv)
 
     def fwd(self, part, part_coff, count, training, coef, save, coff):
+        if training:                                       # the kernel rewrites the running statistics through raw pointers:
+            d_ = self.m.__dict__                           # Tensor._version does not see it, the eval-coefficient cache must
+            d_['_tamgcn_epoch'] = d_.get('_tamgcn_epoch', 0) + 1
         ops.bn_fwd_finalize(part, part_coff, count, self.w, self.b, self.rm, self.rv, self.nbt, self.mom, self.eps,
                             training, coef, save, coff, self.C)
 
@@ -115,6 +121,37 @@ class BN:
 
 def _coef(C_, like):
     return torch.empty(3, C_, device=like.device), torch.empty(2, C_, device=like.device)
+
+
+# ---------------------------------------------------------------------------
+# Eval mode without autograd (the inference callers -- cross-modal attention, ensemble eval, visual.py).
+# BatchNorm is a per-channel affine of the running statistics there: its coefficients depend only on four tensors per
+# BatchNorm, so they are computed once and cached on the module until one of those tensors changes (in-place updates bump
+# Tensor._version, .to() changes data_ptr); the 96 finalize launches of a forward disappear.  The convolution epilogues
+# then finish their consumers' work (tamgcn_conv post_coef / post_act): every MS-TCN branch writes relu(bn(branch) + residual)
+# straight into its channel slice of the block output -- no cat_pre tensor, no add_act pass.
+# ---------------------------------------------------------------------------
+EVAL_FUSED = os.environ.get('TAMGCN_EVAL_FUSED', '1') != '0'
+
+
+def _eval_cached(owner, tag, bns, build):
+    """build() -> value, cached on nn.Module `owner` under `tag` while the tensors of the BN views `bns` are unchanged."""
+    key = tuple((t.data_ptr(), t._version) for bn in bns for t in bn.tensors()) + tuple(bn.m.__dict__.get('_tamgcn_epoch', 0) for bn in bns)
+    cache = owner.__dict__.setdefault('_tamgcn_eval_cache', {})
+    hit = cache.get(tag)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    val = build()
+    cache[tag] = (key, val)
+    return val
+
+
+def _eval_coefs(placed, Ctot, like):
+    """coef [3][Ctot] / save [2][Ctot] of eval-mode BatchNorms placed at channel offsets: [(BN, coff), ...]."""
+    coef, save = _coef(Ctot, like)
+    for bn, coff in placed:
+        bn.fwd(None, 0, 1, False, coef, save, coff)
+    return coef, save
 
 
 # ===========================================================================
@@ -134,11 +171,30 @@ def gcn_forward(x, P, training, save):
     fk = Fork(x.device, 2)
     fk.__enter__()
     d_pre = coef_d = save_d = None
+    ev = None                                          # eval without autograd: cached BatchNorm coefficients, no finalize launches
+    if EVAL_FUSED and not training and not save:
+        bns = [P.bn, P.bno] + ([P.bnd] if P.mode == 'conv' else [])
+
+        def build():
+            cy, sy = _eval_coefs([(P.bn, 0)], Cout, x)
+            co, so = _eval_coefs([(P.bno, 0)], Cout, x)
+            cd, sd_ = _eval_coefs([(P.bnd, 0)], Cout, x) if P.mode == 'conv' else (None, None)
+            if P.mode == 'conv':
+                cdiff = torch.stack((cd[0], -cy[0], cd[2] - cy[2]))
+            elif P.mode == 'identity':
+                cdiff = torch.stack((torch.ones_like(cy[0]), -cy[0], -cy[2]))
+            else:
+                cdiff = torch.stack((-cy[0], torch.zeros_like(cy[0]), -cy[2]))
+            return dict(y=(cy, sy), o=(co, so), d=(cd, sd_), diff=cdiff)
+        ev = _eval_cached(P.bn.m, 'unit_gcn', bns, build)
     if P.mode == 'conv':                               # independent of the CTRGC chain: side stream
         with fk.on(0):
             d_pre, dpart = ops.conv(xs, K=Cin, w=P.Wd, bias=P.bd, M=Cout, stats=training)
-            coef_d, save_d = _coef(Cout, x)
-            P.bnd.fwd(dpart, 0, count, training, coef_d, save_d, 0)
+            if ev is not None:
+                coef_d, save_d = ev['d']
+            else:
+                coef_d, save_d = _coef(Cout, x)
+                P.bnd.fwd(dpart, 0, count, training, coef_d, save_d, 0)
     # pooled joint embeddings (conv1/conv2 commute with the mean over T)
     xbar = ops.tmean(xs, Cin)                                             # (Cin, N, V)
     pq, _ = ops.conv(S(xbar.view(1, Cin, N, V)), K=Cin, w=P.W12, bias=P.B12, M=S_ * 2 * R)
@@ -146,24 +202,30 @@ def gcn_forward(x, P, training, save):
     E = ops.ctrgc_build_E(xs, pq, P.W3, P.B3, P.W4, P.B4, P.PA, P.alpha, Cin, Cout, S_, R) if ((GLOBAL_E or ops.ctrgc_tiled(V)) and R <= 32) else None
     y_pre, ypart, x3 = ops.ctrgc_fwd(xs, pq, P.W3, P.B3, P.W4, P.B4, P.PA, P.alpha, Cin, Cout, S_, R, stats=training,
                                      keep_x3=save and KEEP_X3, E=E)
-    coef_y, save_y = _coef(Cout, x)
-    P.bn.fwd(ypart, 0, count, training, coef_y, save_y, 0)
+    if ev is not None:
+        coef_y, save_y = ev['y']
+    else:
+        coef_y, save_y = _coef(Cout, x)
+        P.bn.fwd(ypart, 0, count, training, coef_y, save_y, 0)
     fk.__exit__()                                      # join: d_pre and its coefficients are needed now
     if P.mode == 'conv':
         res = S(d_pre, coef=coef_d)
-        coef_diff = torch.stack((coef_d[0], -coef_y[0], coef_d[2] - coef_y[2]))
+        coef_diff = ev['diff'] if ev is not None else torch.stack((coef_d[0], -coef_y[0], coef_d[2] - coef_y[2]))
         diff = S(d_pre, y_pre, coef_diff)
     elif P.mode == 'identity':
         res = xs
-        coef_diff = torch.stack((torch.ones_like(coef_y[0]), -coef_y[0], -coef_y[2]))
+        coef_diff = ev['diff'] if ev is not None else torch.stack((torch.ones_like(coef_y[0]), -coef_y[0], -coef_y[2]))
         diff = S(x, y_pre, coef_diff)
     else:                                                                  # residual=False: down(x) = 0
         res = None
-        coef_diff = torch.stack((-coef_y[0], torch.zeros_like(coef_y[0]), -coef_y[2]))
+        coef_diff = ev['diff'] if ev is not None else torch.stack((-coef_y[0], torch.zeros_like(coef_y[0]), -coef_y[2]))
         diff = S(y_pre, None, coef_diff)
     o_pre, opart = ops.conv(diff, K=Cout, w=P.Wo, bias=P.bo, M=Cout, stats=training)
-    coef_o, save_o = _coef(Cout, x)
-    P.bno.fwd(opart, 0, count, training, coef_o, save_o, 0)
+    if ev is not None:
+        coef_o, save_o = ev['o']
+    else:
+        coef_o, save_o = _coef(Cout, x)
+        P.bno.fwd(opart, 0, count, training, coef_o, save_o, 0)
     g = ops.gcn_tail_fwd(S(y_pre, coef=coef_y), S(o_pre, coef=coef_o), res)
     sv = None
     if save:
@@ -270,6 +332,8 @@ def tcn_forward(g, P, training, save, xres=None):
     cnt1, cnt2 = N * T * V, N * T2 * V
     gs = S(g)
     Ch = (nb + 1) * Cb
+    if EVAL_FUSED and not training and not save:
+        return _tcn_forward_eval(g, P, xres), None
     fk = Fork(g.device, 2)
     fk.__enter__()
     cat_pre = ops.empty(N, Cout, T2, V, like=g)
@@ -314,6 +378,49 @@ def tcn_forward(g, P, training, save, xres=None):
         sv = dict(g=g, xres=xres, h_pre=h_pre, cat_pre=cat_pre, r_pre=r_pre, out=out, coef_h=coef_h, save_h=save_h,
                   coef_c=coef_c, save_c=save_c, coef_r=coef_r, save_r=save_r, training=training)
     return out, sv
+
+
+def _tcn_forward_eval(g, P, xres):
+    """Eval mode without autograd: five launches (entry convs, two temporal convs, pooled branch, plain branch) + one
+    for a convolutional residual; every branch finishes relu(bn(branch) + residual) in its own epilogue."""
+    N, Cin, T, V = g.shape
+    Cb, nb, s, Cout = P.Cb, P.nb, P.stride, P.Cout
+    T2 = (T - 1) // s + 1
+    Ch = (nb + 1) * Cb
+    gs = S(g)
+    bns = list(P.bn_in) + list(P.bn_t) + [P.bn_pool, P.bn_l] + ([P.bnr] if P.rmode == 'conv' else [])
+
+    def build():
+        ch, _ = _eval_coefs([(P.bn_in[b], b * Cb) for b in range(nb + 1)], Ch, g)
+        cc, _ = _eval_coefs([(P.bn_t[b], b * Cb) for b in range(nb)] + [(P.bn_pool, nb * Cb), (P.bn_l, (nb + 1) * Cb)], Cout, g)
+        cr = _eval_coefs([(P.bnr, 0)], Cout, g)[0] if P.rmode == 'conv' else None
+        return ch, cc, cr
+    coef_h, coef_c, coef_r = _eval_cached(P.bn_l.m, 'ms_tcn', bns, build)
+    if xres is None:
+        xres = g
+    res = None
+    if P.rmode == 'identity':
+        res = xres
+    elif P.rmode == 'conv':
+        rk = P.rk
+        res, _ = ops.conv(S(xres), K=xres.shape[1], w=P.Wr, bias=P.br, M=Cout, KT=rk, stride=s, pad=(rk - 1) // 2, T_out=T2,
+                          post_coef=coef_r)
+    h_pre, _ = ops.conv(gs, K=Cin, w=P.Win, bias=P.bin, M=Ch)
+    out = ops.empty(N, Cout, T2, V, like=g)
+    fk = Fork(g.device, 2)
+    fk.__enter__()
+    with fk.on(1):
+        ops.conv(gs, K=Cin, w=P.Wl, bias=P.bl, M=Cb, stride=s, y=out, ycoff=(nb + 1) * Cb, T_out=T2, post_coef=coef_c,
+                 post_act=P.relu, add1=res)
+    for b in range(nb):
+        k, d = P.ks[b], P.dils[b]
+        with (fk.on(b) if b > 0 else contextlib.nullcontext()):
+            ops.conv(S(h_pre, coef=coef_h, coff=b * Cb, act=RELU), K=Cb, w=P.Wt[b], bias=P.bt[b], M=Cb, KT=k, dil=d, stride=s,
+                     pad=_tpad(k, d), y=out, ycoff=b * Cb, T_out=T2, post_coef=coef_c, post_act=P.relu, add1=res)
+    with fk.on(0):
+        ops.maxpool_post_fwd(S(h_pre, coef=coef_h, coff=nb * Cb, act=RELU), Cb, s, out, nb * Cb, coef_c, res, P.relu)
+    fk.__exit__()
+    return out
 
 
 def tcn_backward(P, sv, dout, need_dg=True, need_dxres=True):
@@ -425,11 +532,28 @@ def _tcn_backward(P, sv, dout, need_dg=True, need_dxres=True):
 # autograd wrappers.  Parameter order is fixed by the *_tensors() helpers of
 # the modules (models/ctrgcn.py); cfg objects carry everything non-differentiable.
 # ===========================================================================
+# Autograd runs Function.forward with grad mode off, and ctx.needs_input_grad reports the inputs' requires_grad flags even
+# when the CALLER is under torch.no_grad(): the caller's grad mode is recorded by run() (what the modules call instead of
+# apply()), so that inference saves nothing for a backward that cannot happen and takes the fused eval path (row f2).
+_CALL = threading.local()
+
+
+class _Fn(torch.autograd.Function):
+    @classmethod
+    def run(cls, *args):
+        prev = getattr(_CALL, 'grad', True)
+        _CALL.grad = torch.is_grad_enabled()
+        try:
+            return cls.apply(*args)
+        finally:
+            _CALL.grad = prev
+
+
 def _needs(ctx):
-    return any(ctx.needs_input_grad)
+    return getattr(_CALL, 'grad', True) and any(ctx.needs_input_grad)
 
 
-class UnitGCNFn(torch.autograd.Function):
+class UnitGCNFn(_Fn):
     @staticmethod
     def forward(ctx, mod, x, *params):
         P = mod._pack(params)
@@ -444,7 +568,7 @@ class UnitGCNFn(torch.autograd.Function):
         return (None, dx) + tuple(ctx.mod._route(G))
 
 
-class MSTCNFn(torch.autograd.Function):
+class MSTCNFn(_Fn):
     @staticmethod
     def forward(ctx, mod, x, *params):
         P = mod._pack(params)
@@ -462,7 +586,7 @@ class MSTCNFn(torch.autograd.Function):
         return (None, dg) + tuple(ctx.mod._route(G))
 
 
-class TCNGCNUnitFn(torch.autograd.Function):
+class TCNGCNUnitFn(_Fn):
     """relu(tcn1(gcn1(x)) + residual(x)) as one autograd node (models/ctrgcn.py:282-284)."""
 
     @staticmethod
@@ -489,7 +613,7 @@ class TCNGCNUnitFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------
 # stand-alone CTRGC (single subset; A and alpha are forward() arguments)
 # ---------------------------------------------------------------------------
-class CTRGCFn(torch.autograd.Function):
+class CTRGCFn(_Fn):
     @staticmethod
     def forward(ctx, x, A, alpha, w1, b1, w2, b2, w3, b3, w4, b4):
         N, Cin, T, V = x.shape
@@ -533,7 +657,7 @@ class CTRGCFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------
 # conv k x 1 + BatchNorm (TemporalConv, unit_tcn)
 # ---------------------------------------------------------------------------
-class ConvBNFn(torch.autograd.Function):
+class ConvBNFn(_Fn):
     @staticmethod
     def forward(ctx, cfg, x, w, b, gamma, beta):
         k, s, d, pad, bnmod = cfg
@@ -575,7 +699,7 @@ class ConvBNFn(torch.autograd.Function):
 # ===========================================================================
 # stem (data_bn + permutes) and head (global mean-pool + fc) of Model  -- SURVEY.md §8 row f1
 # ===========================================================================
-class StemFn(torch.autograd.Function):
+class StemFn(_Fn):
     """x (N, C, T, V, M) -> data_bn (channels (m, v, c), statistics over (n, t)) -> (N*M, C, T, V)
     (reference models/ctrgcn.py:328-332: two permute copies and a BatchNorm1d)."""
 
@@ -588,9 +712,12 @@ class StemFn(torch.autograd.Function):
         if bn.C != J:
             raise RuntimeError(f'tam_gcn_amd: data_bn has {bn.C} features, input gives {J}')
         training = bn_mod.training
-        coef, save = torch.empty(3, J, device=x.device), torch.empty(2, J, device=x.device)
-        part = ops.stem_stats(x) if training else None
-        bn.fwd(part, 0, N * T, training, coef, save, 0)
+        if EVAL_FUSED and not training and not _needs(ctx):
+            coef, save = _eval_cached(bn_mod, 'stem', [bn], lambda: _eval_coefs([(bn, 0)], J, x))
+        else:
+            coef, save = torch.empty(3, J, device=x.device), torch.empty(2, J, device=x.device)
+            part = ops.stem_stats(x) if training else None
+            bn.fwd(part, 0, N * T, training, coef, save, 0)
         out = ops.stem_apply(x, coef)
         ctx.bn, ctx.training = bn, training
         ctx.save_for_backward(x, save)
@@ -609,7 +736,7 @@ class StemFn(torch.autograd.Function):
         return None, dx, dg, db
 
 
-class HeadFn(torch.autograd.Function):
+class HeadFn(_Fn):
     """x10 (N*M, C, T, V) -> mean over (m, t, v) -> fc  (reference models/ctrgcn.py:343-348, drop_out = 0)."""
 
     @staticmethod
@@ -632,7 +759,7 @@ class HeadFn(torch.autograd.Function):
 # ===========================================================================
 # loss of the harness step -- SURVEY.md §8 row f1 (reference processor/recognition_rgb.py:19, :62: nn.CrossEntropyLoss())
 # ===========================================================================
-class CrossEntropyFn(torch.autograd.Function):
+class CrossEntropyFn(_Fn):
     @staticmethod
     def forward(ctx, logits, labels):
         logits = logits.contiguous()
@@ -655,7 +782,7 @@ class CrossEntropyLoss(torch.nn.Module):
             raise RuntimeError('tam_gcn_amd.CrossEntropyLoss: expected (N, K) fp32 logits and (N,) int64 class indices')
         if not logits.is_cuda:
             raise RuntimeError('tam_gcn_amd: the loss runs on MI355X only (got a CPU tensor); there is no CPU fallback')
-        return CrossEntropyFn.apply(logits, labels)
+        return CrossEntropyFn.run(logits, labels)
 
 
 # ===========================================================================
@@ -674,7 +801,7 @@ def _stgcn_ctrgc_args(x, Ae, W3, B3, Cout):
                 A=Ae.transpose(1, 2).contiguous(), alpha=z(1, device=dev), R=R, K=K)
 
 
-class StGcnFn(torch.autograd.Function):
+class StGcnFn(_Fn):
     """relu(tcn(gcn(x, A)) + residual(x)) of one st_gcn block as one autograd node."""
 
     @staticmethod
@@ -770,7 +897,7 @@ class StGcnFn(torch.autograd.Function):
         return (None, dx, dAe, dw3.reshape(a['K'] * Cout, Cin, 1, 1), db3, dg1, dbe1, dwt, dbt, dg2, dbe2, *gres)
 
 
-class PointwiseConvFn(torch.autograd.Function):
+class PointwiseConvFn(_Fn):
     """1x1 convolution with bias over (N, C, T, V) (ST-GCN's `fcn` applied per position in extract_feature, stgcn.py:218-219)."""
 
     @staticmethod

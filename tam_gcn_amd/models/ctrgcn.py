@@ -122,7 +122,7 @@ class TemporalConv(nn.Module):
 
     def forward(self, x):
         cfg = (self.kernel_size, self.stride, self.dilation, self.pad, self.bn)
-        return Fn.ConvBNFn.apply(cfg, _require_hip(x), self.conv.weight, self.conv.bias, self.bn.weight, self.bn.bias)
+        return Fn.ConvBNFn.run(cfg, _require_hip(x), self.conv.weight, self.conv.bias, self.bn.weight, self.bn.bias)
 
 
 class unit_tcn(nn.Module):
@@ -139,7 +139,7 @@ class unit_tcn(nn.Module):
 
     def forward(self, x):
         cfg = (self.kernel_size, self.stride, 1, self.pad, self.bn)
-        return Fn.ConvBNFn.apply(cfg, _require_hip(x), self.conv.weight, self.conv.bias, self.bn.weight, self.bn.bias)
+        return Fn.ConvBNFn.run(cfg, _require_hip(x), self.conv.weight, self.conv.bias, self.bn.weight, self.bn.bias)
 
 
 # ---------------------------------------------------------------------------
@@ -250,7 +250,7 @@ class MultiScale_TemporalConv(nn.Module):
         return out
 
     def forward(self, x):
-        return Fn.MSTCNFn.apply(self, _require_hip(x), *self._tensors())
+        return Fn.MSTCNFn.run(self, _require_hip(x), *self._tensors())
 
 
 # ---------------------------------------------------------------------------
@@ -285,7 +285,7 @@ class CTRGC(nn.Module):
             A = torch.zeros(V, V, device=x.device)
         if not isinstance(alpha, torch.Tensor):
             alpha = torch.tensor([float(alpha)], device=x.device)
-        return Fn.CTRGCFn.apply(x, A, alpha, *self._tensors())
+        return Fn.CTRGCFn.run(x, A, alpha, *self._tensors())
 
 
 # ---------------------------------------------------------------------------
@@ -395,7 +395,7 @@ class unit_gcn(nn.Module):
 
     def forward(self, x):
         x = _require_hip(x)
-        return Fn.UnitGCNFn.apply(self, x, *self._tensors(x.device))
+        return Fn.UnitGCNFn.run(self, x, *self._tensors(x.device))
 
 
 # ---------------------------------------------------------------------------
@@ -431,7 +431,7 @@ class TCN_GCN_unit(nn.Module):
         if self._rmode == 'conv':
             r = self.residual
             tt = tt + [r.conv.weight, r.conv.bias, r.bn.weight, r.bn.bias]
-        return Fn.TCNGCNUnitFn.apply(self, x, len(gt), *gt, *tt)
+        return Fn.TCNGCNUnitFn.run(self, x, len(gt), *gt, *tt)
 
 
 # ---------------------------------------------------------------------------
@@ -463,7 +463,7 @@ class Model(nn.Module):
             x = x.view(N, T, self.num_point, -1).permute(0, 3, 1, 2).contiguous().unsqueeze(-1)
         N, C, T, V, M = x.size()
         # reference :330-332 (permute, BatchNorm1d, permute back) as one statistics pass + one apply-and-permute pass
-        x = Fn.StemFn.apply(self.data_bn, x, self.data_bn.weight, self.data_bn.bias)
+        x = Fn.StemFn.run(self.data_bn, x, self.data_bn.weight, self.data_bn.bias)
         for i in range(1, 11):
             x = getattr(self, f'l{i}')(x)
         return x, N, M
@@ -473,7 +473,7 @@ class Model(nn.Module):
         if isinstance(self.drop_out, nn.Dropout):          # drop_out > 0: pool here, torch's dropout + linear (reference :343-348)
             x = x.view(N, M, x.size(1), -1).mean(3).mean(1)
             return self.fc(self.drop_out(x))
-        return Fn.HeadFn.apply(x, self.fc.weight, self.fc.bias, M)
+        return Fn.HeadFn.run(x, self.fc.weight, self.fc.bias, M)
 
     def extract_feature(self, x):
         x, N, M = self._blocks(_require_hip(x))

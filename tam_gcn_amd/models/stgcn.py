@@ -78,7 +78,7 @@ class st_gcn(nn.Module):
              self.tcn[3].weight, self.tcn[3].bias]
         if self._rmode == 'conv':
             p += [self.residual[0].weight, self.residual[0].bias, self.residual[1].weight, self.residual[1].bias]
-        return Fn.StGcnFn.apply(self, x, A, *p), A
+        return Fn.StGcnFn.run(self, x, A, *p), A
 
 
 class Model(nn.Module):
@@ -120,7 +120,7 @@ class Model(nn.Module):
             N, T, VC = x.shape
             x = x.view(N, T, self.num_point, -1).permute(0, 3, 1, 2).contiguous().unsqueeze(-1)
         N, C, T, V, M = x.size()
-        x = Fn.StemFn.apply(self.data_bn, x, self.data_bn.weight, self.data_bn.bias)      # reference :180-186
+        x = Fn.StemFn.run(self.data_bn, x, self.data_bn.weight, self.data_bn.bias)      # reference :180-186
         for gcn, importance in zip(self.st_gcn_networks, self.edge_importance):
             x, _ = gcn(x, self.A * importance)
         return x, N, M
@@ -131,13 +131,13 @@ class Model(nn.Module):
             x = x.view(N, M, x.size(1), -1).mean(3).mean(1)
             x = self.drop_out(x)
             return torch.nn.functional.linear(x, self.fcn.weight.view(self.fcn.weight.size(0), -1), self.fcn.bias)
-        return Fn.HeadFn.apply(x, self.fcn.weight.view(self.fcn.weight.size(0), -1), self.fcn.bias, M)   # :193-198
+        return Fn.HeadFn.run(x, self.fcn.weight.view(self.fcn.weight.size(0), -1), self.fcn.bias, M)   # :193-198
 
     def extract_feature(self, x):
         x, N, M = self._blocks(_require_hip(x))
         _, c, t, v = x.size()
         feature = x.view(N, M, c, t, v).permute(0, 2, 3, 4, 1)
-        o = Fn.PointwiseConvFn.apply(x, self.fcn.weight, self.fcn.bias)
+        o = Fn.PointwiseConvFn.run(x, self.fcn.weight, self.fcn.bias)
         output = o.view(N, M, -1, t, v).permute(0, 2, 3, 4, 1)
         return output, feature
 

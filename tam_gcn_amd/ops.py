@@ -99,8 +99,10 @@ def with_slack(t):
 # ---------------------------------------------------------------------------
 def conv(src, K, w, bias, M, KT=1, dil=1, stride=1, pad=0, wmode=0, up=1,
          y=None, ycoff=0, T_out=None, T_y=None, ostride=1, add1=None, add2=None,
-         bcast=None, bcast_scale=0.0, mask=None, aux=None, aux_center=None, auxcoff=0, stats=False):
-    """y (N, yctot, T_y, V); returns (y, stats_part [2][yctot][nparts] or None)."""
+         bcast=None, bcast_scale=0.0, mask=None, aux=None, aux_center=None, auxcoff=0, stats=False,
+         post_coef=None, post_act=0):
+    """y (N, yctot, T_y, V); returns (y, stats_part [2][yctot][nparts] or None).
+    post_coef [3][yctot] / post_act: eval-mode fusion, y = act(c1*(conv + bias) + c0 + adds)."""
     if src.x1.shape[-1] % 4:
         src = S(with_slack(src.x1), with_slack(src.x2), src.coef, src.coff, src.act)
     x = src.x1
@@ -120,7 +122,8 @@ def conv(src, K, w, bias, M, KT=1, dil=1, stride=1, pad=0, wmode=0, up=1,
         for n0, n1 in n_chunks(N, per_clip):
             conv(_slice_src(src, n0, n1), K, w, bias, M, KT, dil, stride, pad, wmode, up, y=y[n0:n1], ycoff=ycoff, T_out=T_out,
                  ostride=ostride, add1=None if add1 is None else add1[n0:n1], add2=None if add2 is None else add2[n0:n1],
-                 bcast=None if bcast is None else bcast[:, n0:n1].contiguous(), bcast_scale=bcast_scale)
+                 bcast=None if bcast is None else bcast[:, n0:n1].contiguous(), bcast_scale=bcast_scale,
+                 post_coef=post_coef, post_act=post_act)
         return y, None
     d = ConvDesc()
     d.src = src.c()
@@ -137,6 +140,9 @@ def conv(src, K, w, bias, M, KT=1, dil=1, stride=1, pad=0, wmode=0, up=1,
         d.mask = C.pointer(mc)
     if aux is not None:
         d.aux, d.aux_center, d.auxctot, d.auxcoff = _ptr(aux), _ptr(aux_center), aux.shape[1], auxcoff
+    if post_coef is not None:
+        d.post_coef, d.post_ctot = _ptr(post_coef), post_coef.shape[1]
+    d.post_act = int(post_act)
     part = None
     lib = _lib_()
     if stats:
@@ -508,6 +514,14 @@ def maxpool_fwd(src, C_, stride, y, ycoff, stats):
     _lib.check(_lib_().tamgcn_maxpool_fwd(C.byref(sc), N, C_, T_in, V, stride, _ptr(y), y.shape[1], ycoff, T_out,
                                           _ptr(part), _stream()), 'tamgcn_maxpool_fwd')
     return part
+
+
+def maxpool_post_fwd(src, C_, stride, y, ycoff, coef, add, relu):
+    """Eval-mode pooled branch finished in place: y[:, ycoff:ycoff+C_] = act(c1 * maxpool(src) + c0 + add)."""
+    N, _, T_in, V = src.x1.shape
+    sc = src.c()
+    _lib.check(_lib_().tamgcn_maxpool_post_fwd(C.byref(sc), N, C_, T_in, V, stride, _ptr(y), y.shape[1], ycoff, y.shape[2],
+                                               _ptr(coef), _ptr(add), int(relu), _stream()), 'tamgcn_maxpool_post_fwd')
 
 
 def maxpool_bwd(gy, src, src_save, C_, stride, d, dcoff):

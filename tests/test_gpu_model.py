@@ -337,3 +337,65 @@ def test_ntu_full_size_properties():
     assert (outp - out[perm]).abs().max() <= 2e-4 * out.abs().max()
     assert (g1 - m.l10.tcn1.branches[0][3].conv.weight.grad).norm() <= 2e-3 * g1.norm()
     assert (g1b - m.l2.gcn1.convs[1].conv3.weight.grad).norm() <= 5e-3 * g1b.norm()
+
+
+def test_eval_fused_path_and_coefficient_cache(monkeypatch):
+    """Row f2: under no_grad in eval mode the blocks run the fused form (cached BatchNorm coefficients, MS-TCN branches that
+    finish relu(bn(.) + residual) in their own epilogues).  It must equal the unfused pipeline, follow a change of the running
+    statistics made by a training step (whose kernel writes them through raw pointers) and of the affine parameters, and
+    launch fewer kernels."""
+    from tam_gcn_amd import functional as Fn, _lib
+    dev = torch.device('cuda:0')
+    m = M.Model(**MODEL_CASES[0][1])
+    fill_state_(m.state_dict(), seed=MODEL_PARAM_SEED)
+    m = m.to(dev).eval()
+    x = make_input((3, 3, 52, 20, 1), seed=MODEL_X_SEED).to(dev)
+
+    def both():
+        with torch.no_grad():
+            monkeypatch.setattr(Fn, 'EVAL_FUSED', True)
+            a, (fa, _) = m(x), m.extract_feature(x)
+            monkeypatch.setattr(Fn, 'EVAL_FUSED', False)
+            b, (fb, _) = m(x), m.extract_feature(x)
+        monkeypatch.setattr(Fn, 'EVAL_FUSED', True)
+        return a, b, fa, fb
+
+    a, b, fa, fb = both()
+    assert (a - b).abs().max() <= 2e-5 * b.abs().max() and (fa - fb).abs().max() <= 2e-5 * fb.abs().max()
+    m.train()                                              # a training step moves every running statistic
+    m(make_input((4, 3, 52, 20, 1), seed=5).to(dev) * 3 + 0.5).sum().backward()
+    m.eval()
+    a2, b2, _, _ = both()
+    assert (a2 - b2).abs().max() <= 2e-5 * b2.abs().max()
+    assert (a2 - a).abs().max() > 1e-3 * a.abs().max()      # the statistics did change: a stale cache would reproduce `a`
+    with torch.no_grad():
+        m.l3.tcn1.branches[0][1].weight.mul_(1.5)          # in-place parameter update (an optimiser step, load_state_dict)
+    a3, b3, _, _ = both()
+    assert (a3 - b3).abs().max() <= 2e-5 * b3.abs().max() and (a3 - a2).abs().max() > 0
+
+    class Count:                                           # ABI launches of one forward
+        def __init__(self, lib):
+            self.lib, self.n = lib, 0
+
+        def __getattr__(self, name):
+            fn = getattr(self.lib, name)
+            if not name.startswith('tamgcn_') or name in ('tamgcn_last_error', 'tamgcn_conv_nparts', 'tamgcn_wgrad_max_split',
+                                                         'tamgcn_ctrgc_tiled_supported', 'tamgcn_ctrgc_tiled_chunks'):
+                return fn
+
+            def w(*args):
+                self.n += 1
+                return fn(*args)
+            return w
+
+    real = _lib.load()
+    counts = []
+    for fused in (True, False):
+        cnt = Count(real)
+        monkeypatch.setattr(_lib, '_lib', cnt)
+        monkeypatch.setattr(Fn, 'EVAL_FUSED', fused)
+        with torch.no_grad():
+            m(x)
+        counts.append(cnt.n)
+    monkeypatch.setattr(_lib, '_lib', real)
+    assert counts[0] <= 135 and counts[0] <= counts[1] - 100, counts
