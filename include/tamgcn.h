@@ -180,6 +180,23 @@ int tamgcn_bn_bwd_finalize(const float* part, int part_ctot, int part_coff, int 
                            int training, float* dgamma, float* dbeta, float* dbias_conv,
                            float* coef, int coef_ctot, int coef_coff, int C, void* stream);
 
+/* Several BatchNorms in one launch: the same arithmetic as the two entry points above, one descriptor per BatchNorm
+ * (fields = their arguments).  A block's forward finalises ~11 BatchNorms and its backward ~9; the ones whose partial sums
+ * are ready together share a launch. */
+typedef struct tamgcn_bn_fwd_desc {
+    const float* part; int part_ctot, part_coff, nparts; double count;
+    const float* gamma; const float* beta; float* running_mean; float* running_var; long long* num_batches_tracked;
+    float momentum, eps; int training;
+    float* coef; float* save; int coef_ctot, coef_coff, C;
+} tamgcn_bn_fwd_desc;
+typedef struct tamgcn_bn_bwd_desc {
+    const float* part; int part_ctot, part_coff, nparts; double count;
+    const float* gamma; const float* save; int save_ctot, save_coff, training;
+    float* dgamma; float* dbeta; float* dbias_conv; float* coef; int coef_ctot, coef_coff, C;
+} tamgcn_bn_bwd_desc;
+int tamgcn_bn_fwd_finalize_multi(const tamgcn_bn_fwd_desc* descs, int n, void* stream);
+int tamgcn_bn_bwd_finalize_multi(const tamgcn_bn_bwd_desc* descs, int n, void* stream);
+
 /* ------------------------------------------------------------------------
  * CTRGC — channel-wise topology refinement graph convolution
  * (reference models/ctrgcn.py:172-177, and the 3-subset sum :252-254).

@@ -44,6 +44,20 @@ class ReduceDesc(C.Structure):
                 ('stride_s', C.c_longlong), ('count', C.c_longlong), ('scale', C.c_float)]
 
 
+class BnFwdDesc(C.Structure):
+    _fields_ = [('part', C.c_void_p), ('part_ctot', C.c_int), ('part_coff', C.c_int), ('nparts', C.c_int), ('count', C.c_double),
+                ('gamma', C.c_void_p), ('beta', C.c_void_p), ('running_mean', C.c_void_p), ('running_var', C.c_void_p),
+                ('num_batches_tracked', C.c_void_p), ('momentum', C.c_float), ('eps', C.c_float), ('training', C.c_int),
+                ('coef', C.c_void_p), ('save', C.c_void_p), ('coef_ctot', C.c_int), ('coef_coff', C.c_int), ('C', C.c_int)]
+
+
+class BnBwdDesc(C.Structure):
+    _fields_ = [('part', C.c_void_p), ('part_ctot', C.c_int), ('part_coff', C.c_int), ('nparts', C.c_int), ('count', C.c_double),
+                ('gamma', C.c_void_p), ('save', C.c_void_p), ('save_ctot', C.c_int), ('save_coff', C.c_int), ('training', C.c_int),
+                ('dgamma', C.c_void_p), ('dbeta', C.c_void_p), ('dbias_conv', C.c_void_p), ('coef', C.c_void_p),
+                ('coef_ctot', C.c_int), ('coef_coff', C.c_int), ('C', C.c_int)]
+
+
 class CtrgcDesc(C.Structure):
     _fields_ = [('N', C.c_int), ('Cin', C.c_int), ('Cout', C.c_int), ('S', C.c_int), ('R', C.c_int),
                 ('T', C.c_int), ('V', C.c_int),
@@ -76,6 +90,8 @@ SIGNATURES = {
     'tamgcn_reduce_sum': (_i, [_p, _i, _ll, _ll, _f, _i, _p, _p]),
     'tamgcn_bn_fwd_finalize': (_i, [_p, _i, _i, _i, _d, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _i, _i, _i, _p]),
     'tamgcn_bn_bwd_finalize': (_i, [_p, _i, _i, _i, _d, _p, _p, _i, _i, _i, _p, _p, _p, _p, _i, _i, _i, _p]),
+    'tamgcn_bn_fwd_finalize_multi': (_i, [C.POINTER(BnFwdDesc), _i, _p]),
+    'tamgcn_bn_bwd_finalize_multi': (_i, [C.POINTER(BnBwdDesc), _i, _p]),
     'tamgcn_tmean': (_i, [_SP, _i, _i, _i, _i, _p, _p]),
     'tamgcn_ctrgc_build_e': (_i, [C.POINTER(CtrgcDesc), _p, _p]),
     'tamgcn_ctrgc_fwd': (_i, [C.POINTER(CtrgcDesc), _p, _p, _p, _p]),

@@ -103,19 +103,26 @@ class BN:
     def tensors(self):
         return (self.w, self.b, self.rm, self.rv)
 
-    def fwd(self, part, part_coff, count, training, coef, save, coff):
+    def fwd(self, part, part_coff, count, training, coef, save, coff, batch=None):
+        """batch (ops.BNBatch): only registered; batch.flush() launches it with the others."""
         if training:                                       # the kernel rewrites the running statistics through raw pointers:
             d_ = self.m.__dict__                           # Tensor._version does not see it, the eval-coefficient cache must
             d_['_tamgcn_epoch'] = d_.get('_tamgcn_epoch', 0) + 1
+        if batch is not None:
+            batch.fwd(part, part_coff, count, self.w, self.b, self.rm, self.rv, self.nbt, self.mom, self.eps, training, coef, save, coff, self.C)
+            return
         ops.bn_fwd_finalize(part, part_coff, count, self.w, self.b, self.rm, self.rv, self.nbt, self.mom, self.eps,
                             training, coef, save, coff, self.C)
 
-    def bwd(self, part, part_coff, count, save, save_coff, training, coef, coff, want_dbias=False):
+    def bwd(self, part, part_coff, count, save, save_coff, training, coef, coff, want_dbias=False, batch=None):
         dev = self.w.device
         dg = torch.empty(self.C, device=dev)
         db = torch.empty(self.C, device=dev)
         dbias = torch.empty(self.C, device=dev) if want_dbias else None
-        ops.bn_bwd_finalize(part, part_coff, count, self.w, save, save_coff, training, dg, db, dbias, coef, coff, self.C)
+        if batch is not None:
+            batch.bwd(part, part_coff, count, self.w, save, save_coff, training, dg, db, dbias, coef, coff, self.C)
+        else:
+            ops.bn_bwd_finalize(part, part_coff, count, self.w, save, save_coff, training, dg, db, dbias, coef, coff, self.C)
         return dg, db, dbias
 
 
@@ -192,9 +199,6 @@ def gcn_forward(x, P, training, save):
             d_pre, dpart = ops.conv(xs, K=Cin, w=P.Wd, bias=P.bd, M=Cout, stats=training)
             if ev is not None:
                 coef_d, save_d = ev['d']
-            else:
-                coef_d, save_d = _coef(Cout, x)
-                P.bnd.fwd(dpart, 0, count, training, coef_d, save_d, 0)
     # pooled joint embeddings (conv1/conv2 commute with the mean over T)
     xbar = ops.tmean(xs, Cin)                                             # (Cin, N, V)
     pq, _ = ops.conv(S(xbar.view(1, Cin, N, V)), K=Cin, w=P.W12, bias=P.B12, M=S_ * 2 * R)
@@ -202,12 +206,17 @@ def gcn_forward(x, P, training, save):
     E = ops.ctrgc_build_E(xs, pq, P.W3, P.B3, P.W4, P.B4, P.PA, P.alpha, Cin, Cout, S_, R) if ((GLOBAL_E or ops.ctrgc_tiled(V)) and R <= 32) else None
     y_pre, ypart, x3 = ops.ctrgc_fwd(xs, pq, P.W3, P.B3, P.W4, P.B4, P.PA, P.alpha, Cin, Cout, S_, R, stats=training,
                                      keep_x3=save and KEEP_X3, E=E)
+    fk.__exit__()                                      # join: d_pre is needed now
     if ev is not None:
         coef_y, save_y = ev['y']
-    else:
+    else:                                              # bn and down's BatchNorm in one launch
+        bb = ops.BNBatch()
         coef_y, save_y = _coef(Cout, x)
-        P.bn.fwd(ypart, 0, count, training, coef_y, save_y, 0)
-    fk.__exit__()                                      # join: d_pre and its coefficients are needed now
+        P.bn.fwd(ypart, 0, count, training, coef_y, save_y, 0, batch=bb)
+        if P.mode == 'conv':
+            coef_d, save_d = _coef(Cout, x)
+            P.bnd.fwd(dpart, 0, count, training, coef_d, save_d, 0, batch=bb)
+        bb.flush()
     if P.mode == 'conv':
         res = S(d_pre, coef=coef_d)
         coef_diff = ev['diff'] if ev is not None else torch.stack((coef_d[0], -coef_y[0], coef_d[2] - coef_y[2]))
@@ -268,7 +277,14 @@ def _gcn_backward(P, sv, dg, need_dx=True, extra_dx=None):
     dyb, dres, part2 = ops.gcn_mid_bwd(dsum, ddiff, y_pre, sv['save_y'], d_pre if P.mode == 'conv' else None,
                                        sv['save_d'], want_dres=P.mode != 'zero')
     coefb_y = torch.empty(3, Cout, device=x.device)
-    G['bn.w'], G['bn.b'], _ = P.bn.bwd(part2, 0, count, sv['save_y'], 0, training, coefb_y, 0)
+    bb = ops.BNBatch()                                 # bn and down's BatchNorm: both from gcn_mid_bwd's moments, one launch
+    G['bn.w'], G['bn.b'], _ = P.bn.bwd(part2, 0, count, sv['save_y'], 0, training, coefb_y, 0, batch=bb)
+    coefb_d = None
+    if P.mode == 'conv':
+        coefb_d = torch.empty(3, Cout, device=x.device)
+        G['bnd.w'], G['bnd.b'], G['bd'] = P.bnd.bwd(part2[2:4], 0, count, sv['save_d'], 0, training, coefb_d, 0,
+                                                     want_dbias=True, batch=bb)
+    bb.flush()
     dy = S(dyb, y_pre, coefb_y)
     # CTRGC
     xs = S(x)
@@ -293,9 +309,6 @@ def _gcn_backward(P, sv, dg, need_dx=True, extra_dx=None):
                          bcast=dxbar.view(Cin, N, V), bcast_scale=1.0 / T,
                          add1=dres if P.mode == 'identity' else None, add2=extra_dx)
     if P.mode == 'conv':
-        coefb_d = torch.empty(3, Cout, device=x.device)
-        G['bnd.w'], G['bnd.b'], G['bd'] = P.bnd.bwd(part2[2:4], 0, count, sv['save_d'], 0, training, coefb_d, 0,
-                                                     want_dbias=True)
         gyd = S(dres, d_pre, coefb_d)
         fk.refork()
         with fk.on(0):
@@ -338,14 +351,17 @@ def tcn_forward(g, P, training, save, xres=None):
     fk.__enter__()
     cat_pre = ops.empty(N, Cout, T2, V, like=g)
     coef_c, save_c = _coef(Cout, g)
+    bo = ops.BNBatch()                                 # the branches' output norms: one launch after the join
     with fk.on(1):                                     # the plain 1x1 branch only needs g
         _, lpart = ops.conv(gs, K=Cin, w=P.Wl, bias=P.bl, M=Cb, stride=s, y=cat_pre, ycoff=(nb + 1) * Cb, T_out=T2,
                             stats=training)
-        P.bn_l.fwd(lpart, (nb + 1) * Cb, cnt2, training, coef_c, save_c, (nb + 1) * Cb)
+        P.bn_l.fwd(lpart, (nb + 1) * Cb, cnt2, training, coef_c, save_c, (nb + 1) * Cb, batch=bo)
     h_pre, hpart = ops.conv(gs, K=Cin, w=P.Win, bias=P.bin, M=Ch, stats=training)
     coef_h, save_h = _coef(Ch, g)
+    bi = ops.BNBatch()                                 # the three entry norms: one launch
     for b in range(nb + 1):
-        P.bn_in[b].fwd(hpart, b * Cb, cnt1, training, coef_h, save_h, b * Cb)
+        P.bn_in[b].fwd(hpart, b * Cb, cnt1, training, coef_h, save_h, b * Cb, batch=bi)
+    bi.flush()
     fk.refork()                                        # h_pre and coef_h are ready on main
     for b in range(nb):
         k, d = P.ks[b], P.dils[b]
@@ -353,10 +369,10 @@ def tcn_forward(g, P, training, save, xres=None):
             _, part = ops.conv(S(h_pre, coef=coef_h, coff=b * Cb, act=RELU), K=Cb, w=P.Wt[b], bias=P.bt[b], M=Cb,
                                KT=k, dil=d, stride=s, pad=_tpad(k, d), y=cat_pre, ycoff=b * Cb, T_out=T2,
                                stats=training)
-            P.bn_t[b].fwd(part, b * Cb, cnt2, training, coef_c, save_c, b * Cb)
+            P.bn_t[b].fwd(part, b * Cb, cnt2, training, coef_c, save_c, b * Cb, batch=bo)
     with fk.on(0):
         part = ops.maxpool_fwd(S(h_pre, coef=coef_h, coff=nb * Cb, act=RELU), Cb, s, cat_pre, nb * Cb, stats=training)
-        P.bn_pool.fwd(part, nb * Cb, cnt2, training, coef_c, save_c, nb * Cb)
+        P.bn_pool.fwd(part, nb * Cb, cnt2, training, coef_c, save_c, nb * Cb, batch=bo)
     r_pre = coef_r = save_r = None
     if xres is None:
         xres = g
@@ -367,11 +383,12 @@ def tcn_forward(g, P, training, save, xres=None):
         r_pre, rpart = ops.conv(S(xres), K=xres.shape[1], w=P.Wr, bias=P.br, M=Cout, KT=rk, stride=s,
                                 pad=(rk - 1) // 2, T_out=T2, stats=training)
         coef_r, save_r = _coef(Cout, g)
-        P.bnr.fwd(rpart, 0, cnt2, training, coef_r, save_r, 0)
+        P.bnr.fwd(rpart, 0, cnt2, training, coef_r, save_r, 0, batch=bo)
         res = S(r_pre, coef=coef_r)
     else:
         res = None
     fk.__exit__()                                      # join all branches
+    bo.flush()
     out = ops.add_act_fwd(S(cat_pre, coef=coef_c), res, P.relu, Cout)
     sv = None
     if save:
@@ -445,17 +462,24 @@ def _tcn_backward(P, sv, dout, need_dg=True, need_dxres=True):
     if dz is None:
         dz = dout
     coefb_c = torch.empty(3, Cout, device=g.device)
+    bo = ops.BNBatch()                                 # every output norm of the block (and the residual's) in one launch
     G['bn_t'] = []
     G['bt'] = []
     for b in range(nb):
-        dgam, dbet, dbias = P.bn_t[b].bwd(part, b * Cb, cnt2, sv['save_c'], b * Cb, training, coefb_c, b * Cb, True)
+        dgam, dbet, dbias = P.bn_t[b].bwd(part, b * Cb, cnt2, sv['save_c'], b * Cb, training, coefb_c, b * Cb, True, batch=bo)
         G['bn_t'].append((dgam, dbet))
         G['bt'].append(dbias)
-    dgam, dbet, _ = P.bn_pool.bwd(part, nb * Cb, cnt2, sv['save_c'], nb * Cb, training, coefb_c, nb * Cb)
+    dgam, dbet, _ = P.bn_pool.bwd(part, nb * Cb, cnt2, sv['save_c'], nb * Cb, training, coefb_c, nb * Cb, batch=bo)
     G['bn_pool'] = (dgam, dbet)
     dgam, dbet, G['bl'] = P.bn_l.bwd(part, (nb + 1) * Cb, cnt2, sv['save_c'], (nb + 1) * Cb, training, coefb_c,
-                                     (nb + 1) * Cb, True)
+                                     (nb + 1) * Cb, True, batch=bo)
     G['bn_l'] = (dgam, dbet)
+    coefb_r = None
+    if P.rmode == 'conv':
+        coefb_r = torch.empty(3, Cout, device=g.device)
+        dgam, dbet, G['br'] = P.bnr.bwd(part[2:4], 0, cnt2, sv['save_r'], 0, training, coefb_r, 0, True, batch=bo)
+        G['bnr'] = (dgam, dbet)
+    bo.flush()
 
     def gcat(coff):
         return S(dz, cat_pre, coefb_c, coff=coff)
@@ -468,6 +492,7 @@ def _tcn_backward(P, sv, dout, need_dg=True, need_dxres=True):
     # temporal branches: branch 0's data gradient on main, the others' beside it (small, latency-bound launches);
     # every branch's weight gradient follows on a side stream
     marks = []
+    bi = ops.BNBatch()                                 # the entry norms' backward: one launch once every dh slice is written
     for b in range(nb):
         k, d = P.ks[b], P.dils[b]
         pad = _tpad(k, d)
@@ -476,9 +501,9 @@ def _tcn_backward(P, sv, dout, need_dg=True, need_dxres=True):
                              pad=(k - 1) * d - pad, wmode=1, up=s, y=dh, ycoff=b * Cb, T_out=T,
                              mask=S(h_pre, coef=sv['coef_h'], coff=b * Cb), aux=h_pre, aux_center=sv['save_h'], auxcoff=b * Cb,
                              stats=True)
-            dgam, dbet, dbias = P.bn_in[b].bwd(hp, b * Cb, cnt1, sv['save_h'], b * Cb, training, coefb_h, b * Cb, True)
+        dgam, dbet, dbias = P.bn_in[b].bwd(hp, b * Cb, cnt1, sv['save_h'], b * Cb, training, coefb_h, b * Cb, True, batch=bi)
         if b > 0:
-            marks.append(fk.mark(b))                   # dh slice + coefficients of branch b done (its wgrad is not awaited)
+            marks.append(fk.mark(b))                   # dh slice and moments of branch b done (its wgrad is not awaited)
         G['bn_in'].append((dgam, dbet))
         dbin.append(dbias)
         with fk.on(b):
@@ -486,11 +511,12 @@ def _tcn_backward(P, sv, dout, need_dg=True, need_dxres=True):
                                      KT=k, dil=d, stride=s, pad=pad))
     hp = ops.maxpool_bwd(gcat(nb * Cb), S(h_pre, coef=sv['coef_h'], coff=nb * Cb, act=RELU), sv['save_h'], Cb, s, dh,
                          nb * Cb)
-    dgam, dbet, dbias = P.bn_in[nb].bwd(hp, nb * Cb, cnt1, sv['save_h'], nb * Cb, training, coefb_h, nb * Cb, True)
+    dgam, dbet, dbias = P.bn_in[nb].bwd(hp, nb * Cb, cnt1, sv['save_h'], nb * Cb, training, coefb_h, nb * Cb, True, batch=bi)
     G['bn_in'].append((dgam, dbet))
     dbin.append(dbias)
     for ev in marks:
-        fk.wait(ev)                                    # the other branches' slices of dh / coefb_h
+        fk.wait(ev)                                    # the other branches' slices of dh and their moments
+    bi.flush()
     G['bin'] = dbin                                    # per branch (separate tensors: autograd adopts them without a copy)
     gs = S(g)
     gyh = S(dh, h_pre, coefb_h)
@@ -507,9 +533,6 @@ def _tcn_backward(P, sv, dout, need_dg=True, need_dxres=True):
     if P.rmode == 'identity':
         dxres = dz
     elif P.rmode == 'conv':
-        coefb_r = torch.empty(3, Cout, device=g.device)
-        dgam, dbet, G['br'] = P.bnr.bwd(part[2:4], 0, cnt2, sv['save_r'], 0, training, coefb_r, 0, True)
-        G['bnr'] = (dgam, dbet)
         gyr = S(dz, r_pre, coefb_r)
         rk = P.rk
         rpad = (rk - 1) // 2

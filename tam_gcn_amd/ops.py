@@ -281,6 +281,44 @@ def bn_fwd_finalize(part, part_coff, count, gamma, beta, rmean, rvar, nbt, momen
                                           coef.shape[1], coff, C_, _stream()), 'tamgcn_bn_fwd_finalize')
 
 
+class BNBatch:
+    """Collects BatchNorm finalisations whose partial sums are ready together and issues them as ONE launch per
+    direction on the stream current at flush() (tamgcn_bn_*_finalize_multi)."""
+
+    def __init__(self):
+        self.f, self.b, self.keep = [], [], []
+
+    def fwd(self, part, part_coff, count, gamma, beta, rmean, rvar, nbt, momentum, eps, training, coef, save, coff, C_):
+        d = _lib.BnFwdDesc()
+        d.part = _ptr(part)
+        d.part_ctot, d.nparts = (part.shape[1], part.shape[2]) if part is not None else (0, 0)
+        d.part_coff, d.count = part_coff, float(count)
+        d.gamma, d.beta, d.running_mean, d.running_var, d.num_batches_tracked = _ptr(gamma), _ptr(beta), _ptr(rmean), _ptr(rvar), _ptr(nbt)
+        d.momentum, d.eps, d.training = momentum, eps, int(training)
+        d.coef, d.save, d.coef_ctot, d.coef_coff, d.C = _ptr(coef), _ptr(save), coef.shape[1], coff, C_
+        self.f.append(d)
+        self.keep += [part, coef, save]
+
+    def bwd(self, part, part_coff, count, gamma, save, save_coff, training, dgamma, dbeta, dbias, coef, coff, C_):
+        d = _lib.BnBwdDesc()
+        d.part, d.part_ctot, d.part_coff, d.nparts, d.count = _ptr(part), part.shape[1], part_coff, part.shape[2], float(count)
+        d.gamma, d.save, d.save_ctot, d.save_coff, d.training = _ptr(gamma), _ptr(save), save.shape[1], save_coff, int(training)
+        d.dgamma, d.dbeta, d.dbias_conv = _ptr(dgamma), _ptr(dbeta), _ptr(dbias)
+        d.coef, d.coef_ctot, d.coef_coff, d.C = _ptr(coef), coef.shape[1], coff, C_
+        self.b.append(d)
+        self.keep += [part, save, coef, dgamma, dbeta, dbias]
+
+    def flush(self):
+        lib = _lib_()
+        if self.f:
+            arr = (_lib.BnFwdDesc * len(self.f))(*self.f)
+            _lib.check(lib.tamgcn_bn_fwd_finalize_multi(arr, len(self.f), _stream()), 'tamgcn_bn_fwd_finalize_multi')
+        if self.b:
+            arr = (_lib.BnBwdDesc * len(self.b))(*self.b)
+            _lib.check(lib.tamgcn_bn_bwd_finalize_multi(arr, len(self.b), _stream()), 'tamgcn_bn_bwd_finalize_multi')
+        self.f, self.b, self.keep = [], [], []
+
+
 def bn_bwd_finalize(part, part_coff, count, gamma, save, save_coff, training, dgamma, dbeta, dbias, coef, coff, C_):
     lib = _lib_()
     _lib.check(lib.tamgcn_bn_bwd_finalize(_ptr(part), part.shape[1], part_coff, part.shape[2], float(count),

@@ -398,4 +398,4 @@ def test_eval_fused_path_and_coefficient_cache(monkeypatch):
             m(x)
         counts.append(cnt.n)
     monkeypatch.setattr(_lib, '_lib', real)
-    assert counts[0] <= 135 and counts[0] <= counts[1] - 100, counts
+    assert counts[0] <= 125 and counts[0] <= counts[1] - 40, counts
