@@ -65,6 +65,10 @@ const char* tamgcn_last_kernel(void);
  * Takes effect for launches issued after the call; not a stream operation. */
 int         tamgcn_get_split_mode(void);
 int         tamgcn_set_split_mode(int mode);
+/* Opt-in (initial value from TAMGCN_SPLIT3_FWD, default 0): with split mode >= 1 the FORWARD 1x1 convolutions into >= 128
+ * channels run as a three-term bf16 split (six v_mfma_f32_16x16x32_bf16 per K = 32 step: hh, hm, mh, hl, lh, mm), which
+ * reproduces the fp32 product to ~1.2e-7 relative (outputs within 1e-6 of the exact kernels, tools/split3_check.py). */
+int         tamgcn_set_split3_fwd(int on);
 /* bytes of LDS the CTRGC kernels need for (S subsets, V joints, R rel-channels): the fused LDS-resident family for
  * V in {20, 25}, the tiled large-skeleton family (tamgcn_ctrgc_tiled_*) for V in {32, 64};
  * <0 if the shape is unsupported.  Lets the host fail early and loudly. */

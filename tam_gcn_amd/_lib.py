@@ -76,6 +76,7 @@ SIGNATURES = {
     'tamgcn_ctrgc_lds_bytes': (_i, [_i, _i, _i]),
     'tamgcn_get_split_mode': (_i, []),
     'tamgcn_set_split_mode': (_i, [_i]),
+    'tamgcn_set_split3_fwd': (_i, [_i]),
     'tamgcn_conv_nparts': (_i, [C.POINTER(ConvDesc)]),
     'tamgcn_conv': (_i, [C.POINTER(ConvDesc), _p]),
     'tamgcn_wgrad_max_split': (_i, [C.POINTER(WgradDesc)]),

@@ -815,6 +815,9 @@ __global__ __launch_bounds__(G_NT, 2) void conv1x1_glds_kernel(const ConvArgs a,
 // ===========================================================================
 constexpr int GS_BK = 32, GS_BMT = 128, GS_MT = 4, GS_NST = 2;
 
+// TERMS = 2: the two-term split (backward: weight view w[k][m], wmode 1);  TERMS = 3, WM0: the three-term split for the
+// FORWARD 1x1 convolutions into >= 128 channels (weight rows w[m][k]), fp32-exact to rounding, with BatchNorm moments.
+template <int TERMS, bool WM0>
 __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs a, int ntt, int nmt) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int BK = GS_BK;
@@ -822,7 +825,8 @@ __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs
     constexpr int MAXB = ((BK / 4) * 5 + 7) / 8;                  // B pieces per wave and chunk
     constexpr int NAP = BK * GS_BMT / 256 / 8;                    // A pieces per wave and chunk (2)
     float* cf = smem + GS_NST * STG;                              // [3][K]
-    float* Ss = cf + 3 * a.K;
+    float* Ss = cf + 3 * a.K;                                     // [2][4*BM] row moments
+    float* Bc = Ss + 2 * 4 * BM;                                  // [128] per-row constant of the linear prologue
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kq = lane >> 4, wm = wave >> 2, wn = wave & 3;
@@ -881,10 +885,18 @@ __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs
 #pragma unroll
     for (int i = 0; i < NAP; ++i) {
         const int piece = wave * NAP + i;                         // 0..15
-        const int kr = piece * 2 + (lane >> 5), q = lane & 31;    // k row in the chunk, physical channel quad
-        const int qs = q ^ ((kr & 1) << 2);                       // source quad: rows of different parity sit 16 banks apart
-        a_ok[i] = m0 + qs * 4 < a.M;                              // M % 4 == 0 (host)
-        a_rel[i] = kr * (int)a.ws_k + (m0 + qs * 4) * (int)a.ws_m;
+        if constexpr (WM0) {
+            // weight rows w[m][k]: a piece = 8 rows x 32 taps (128 B each); lane (r, q) fetches source quad q ^ (m & 7), so
+            // that the 16 rows a fragment read touches spread over 8 quad positions (2-way instead of 16-way conflicts)
+            const int m = piece * 8 + (lane >> 3), q = lane & 7;
+            a_ok[i] = m0 + m < a.M;
+            a_rel[i] = (m0 + (a_ok[i] ? m : 0)) * (int)a.ws_m + 4 * (q ^ (m & 7));
+        } else {
+            const int kr = piece * 2 + (lane >> 5), q = lane & 31;    // k row in the chunk, physical channel quad
+            const int qs = q ^ ((kr & 1) << 2);                       // source quad: rows of different parity sit 16 banks apart
+            a_ok[i] = m0 + qs * 4 < a.M;                              // M % 4 == 0 (host)
+            a_rel[i] = kr * (int)a.ws_k + (m0 + qs * 4) * (int)a.ws_m;
+        }
         a_dst[i] = BK * G_PBMAX + piece * 256;
     }
     nissue += NAP;
@@ -916,7 +928,7 @@ __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs
 #pragma unroll
     for (int mt = 0; mt < GS_MT; ++mt) {
         const int m = wm * 64 + mt * 16 + j;
-        aoff[mt] = (((m >> 2) ^ ((kq & 1) << 2)) << 2) + (m & 3);
+        aoff[mt] = WM0 ? m : (((m >> 2) ^ ((kq & 1) << 2)) << 2) + (m & 3);
     }
     f32x4 acc[GS_MT][G_CWT];
 #pragma unroll
@@ -941,12 +953,18 @@ __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs
 #pragma unroll
             for (int e = 0; e < 8; ++e) { cs[e] = cc1[4 * e]; c0[e] = c < nchk ? cf[2 * K + k0 + 4 * e + kq] : 0.f; }
         }
-        bf16x8_t ah[GS_MT], al[GS_MT];
+        bf16x8_t ah[GS_MT], am[GS_MT], al[GS_MT];
 #pragma unroll
         for (int mt = 0; mt < GS_MT; ++mt) {
             f32x4 v0, v1;
+            if constexpr (WM0) {
+                const int m = aoff[mt];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v0[e] = As[(4 * e + kq) * GS_BMT + aoff[mt]]; v1[e] = As[(4 * (e + 4) + kq) * GS_BMT + aoff[mt]]; }
+                for (int e = 0; e < 4; ++e) { v0[e] = As[m * BK + 4 * (e ^ (m & 7)) + kq]; v1[e] = As[m * BK + 4 * ((e + 4) ^ (m & 7)) + kq]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v0[e] = As[(4 * e + kq) * GS_BMT + aoff[mt]]; v1[e] = As[(4 * (e + 4) + kq) * GS_BMT + aoff[mt]]; }
+            }
             if (!plain) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -954,17 +972,25 @@ __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs
                     v0[e] *= cs[e]; v1[e] *= cs[e + 4];
                 }
             }
-            split_bf16x8(v0, v1, ah[mt], al[mt]);
+            if constexpr (TERMS == 3) split3_bf16x8(v0, v1, ah[mt], am[mt], al[mt]);
+            else split_bf16x8(v0, v1, ah[mt], al[mt]);
         }
 #pragma unroll
         for (int cc = 0; cc < G_CWT; ++cc) {
             f32x4 v0, v1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v0[e] = st[(4 * e + kq) * LB + bslot[cc]]; v1[e] = st[(4 * (e + 4) + kq) * LB + bslot[cc]]; }
-            bf16x8_t bh, bl;
-            split_bf16x8(v0, v1, bh, bl);
+            if constexpr (TERMS == 3) {
+                bf16x8_t bh, bm, bl;
+                split3_bf16x8(v0, v1, bh, bm, bl);
 #pragma unroll
-            for (int mt = 0; mt < GS_MT; ++mt) acc[mt][cc] = mfma_split(ah[mt], al[mt], bh, bl, acc[mt][cc]);
+                for (int mt = 0; mt < GS_MT; ++mt) acc[mt][cc] = mfma_split3(ah[mt], am[mt], al[mt], bh, bm, bl, acc[mt][cc]);
+            } else {
+                bf16x8_t bh, bl;
+                split_bf16x8(v0, v1, bh, bl);
+#pragma unroll
+                for (int mt = 0; mt < GS_MT; ++mt) acc[mt][cc] = mfma_split(ah[mt], al[mt], bh, bl, acc[mt][cc]);
+            }
         }
     }
 
@@ -972,7 +998,9 @@ __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs
     // one column-wave per row group publishes it (Ss is free: this kernel produces no moments).
     constexpr int PT = G_CWT * 64 + 4, RP = 32;
     float* Tt = smem;
-    float* Bc = Ss;                                               // [128] per-row constant
+    if (a.stats_part) {
+        for (int e = tid; e < 2 * 4 * BM; e += G_NT) Ss[e] = 0.f;
+    }
 #pragma unroll
     for (int mt = 0; mt < GS_MT; ++mt) {
         float t = bsum[mt];
@@ -997,6 +1025,14 @@ __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs
         }
         __syncthreads();
         staged_rows<G_NT>(a, Tt, PT, RP, r0, GS_BMT, m0, n, t0, ncols, Ss + 0, V, 0);
+    }
+    if (a.stats_part) {
+        __syncthreads();
+        if (tid < 2 * GS_BMT) {
+            int stt = tid / GS_BMT, row = tid - stt * GS_BMT;
+            int m = m0 + row;
+            if (m < a.M) a.stats_part[((long long)stt * a.stats_ctot + a.stats_coff + m) * a.nparts + g] = Ss[stt * 4 * BM + row];
+        }
     }
 }
 
@@ -1111,17 +1147,27 @@ extern "C" int tamgcn_conv(const tamgcn_conv_desc* d, void* stream) {
     const bool aligned16 = (((uintptr_t)d->src.x1 | (uintptr_t)(d->src.x2 ? d->src.x2 : d->src.x1) | (uintptr_t)d->w) & 15) == 0;
     const bool glds = p.vec && p.flat && d->K % 16 == 0 && p.LB >= 64 && p.LB <= G_PBMAX && (p.LB & 3) == 0 &&
                       aligned16 && (long long)d->K * d->T_in * d->V < (1LL << 30);
-    const bool big = glds && tamgcn_split_mode() >= 1 && d->wmode == 1 && d->src.act == 0 && d->M >= 128 && d->M % 4 == 0 &&
-                     d->K % GS_BK == 0 && !d->stats_part;
-    if (big) {
+    // 128-row tiles on the bf16 matrix cores, operands split in registers (linear prologue only: it folds into the weights):
+    //   backward (w[k][m]): two-term split, no moments;  forward (w[m][k]): three-term split (fp32-exact), with moments.
+    const size_t lds_split = sizeof(float) * ((size_t)GS_NST * (GS_BK * G_PBMAX + GS_BK * GS_BMT) + 3 * (size_t)d->K + 2 * 4 * BM + GS_BMT);
+    const bool big_ok = glds && tamgcn_split_mode() >= 1 && d->src.act == 0 && d->M >= 128 && d->M % 4 == 0 && d->K % GS_BK == 0 &&
+                        lds_split <= 160 * 1024 && !d->post_coef;
+    const bool big = big_ok && d->wmode == 1 && !d->stats_part;
+    const bool big3 = big_ok && d->wmode == 0 && tamgcn_split3_fwd();
+    if (big || big3) {
         const int nmt = ceil_div(d->M, GS_BMT);
         const unsigned nblk = (unsigned)(d->N * p.ntt * nmt);
-        static tg_devmask fs = 0;
-        const size_t lds = sizeof(float) * ((size_t)GS_NST * (GS_BK * G_PBMAX + GS_BK * GS_BMT) + 3 * (size_t)d->K + 2 * 4 * BM);
-        tg_allow_lds((const void*)conv1x1_glds_split_kernel, 160 * 1024, &fs);
-        TG_CHECK(lds <= 160 * 1024, "tamgcn_conv: K=%d too large for the split data-gradient kernel", d->K);
-        hipLaunchKernelGGL(conv1x1_glds_split_kernel, dim3(nblk), dim3(G_NT), lds, (hipStream_t)stream, a, p.ntt, nmt);
-        tamgcn_note_kernel("conv1x1_glds_split_kernel");
+        if (big3) {
+            static tg_devmask f3 = 0;
+            tg_allow_lds((const void*)conv1x1_glds_split_kernel<3, true>, 160 * 1024, &f3);
+            hipLaunchKernelGGL((conv1x1_glds_split_kernel<3, true>), dim3(nblk), dim3(G_NT), lds_split, (hipStream_t)stream, a, p.ntt, nmt);
+            tamgcn_note_kernel("conv1x1_glds_split_kernel<3, fwd>");
+        } else {
+            static tg_devmask fs = 0;
+            tg_allow_lds((const void*)conv1x1_glds_split_kernel<2, false>, 160 * 1024, &fs);
+            hipLaunchKernelGGL((conv1x1_glds_split_kernel<2, false>), dim3(nblk), dim3(G_NT), lds_split, (hipStream_t)stream, a, p.ntt, nmt);
+            tamgcn_note_kernel("conv1x1_glds_split_kernel");
+        }
     } else if (glds) {
         const int nmt = ceil_div(d->M, G_BMT);
         const unsigned nblk = (unsigned)(d->N * p.ntt * nmt);

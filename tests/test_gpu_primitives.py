@@ -378,3 +378,34 @@ def test_cross_entropy_against_torch():
         (ref * 1.7).backward()
         assert abs(float(loss) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
         assert (logits.grad.double() - ref_l.grad).abs().max() <= 2e-7
+
+
+def test_three_term_split_forward_gemm_matches_exact_kernels():
+    """conv1x1_glds_split_kernel<3, fwd> (opt-in, TAMGCN_SPLIT3_FWD): six bf16 MFMAs per K = 32 step reproduce the exact
+    fp32-input MFMA kernels to 1e-6 of the output scale, BatchNorm moments included, over one / two sources, partial
+    tiles, V = 20 / 25 / 64."""
+    from tam_gcn_amd import _lib, ops
+    from tam_gcn_amd.ops import S
+    lib = _lib.load()
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(0)
+    r = lambda *s: (torch.rand(*s, generator=g) * 2 - 1).to(dev)      # noqa: E731
+    prev = lib.tamgcn_get_split_mode()
+    try:
+        for (N, K, M, T, V, two) in [(4, 64, 128, 7, 20, 0), (4, 128, 128, 7, 20, 1), (4, 256, 256, 4, 20, 1), (3, 64, 192, 13, 20, 0),
+                                     (2, 128, 384, 33, 25, 0), (2, 256, 768, 12, 64, 0)]:
+            x1, x2 = r(N, K, T, V), r(N, K, T, V)
+            coef = torch.stack((r(K) + 1.5, r(K), r(K)))
+            w, b = r(M, K) * K ** -0.5, r(M)
+            src = S(x1, x2, coef) if two else S(x1)
+            lib.tamgcn_set_split_mode(0)
+            y0, p0 = ops.conv(src, K=K, w=w, bias=b, M=M, stats=True)
+            lib.tamgcn_set_split_mode(1); lib.tamgcn_set_split3_fwd(1)
+            y1, p1 = ops.conv(src, K=K, w=w, bias=b, M=M, stats=True)
+            assert b'split_kernel<3' in lib.tamgcn_last_kernel()
+            lib.tamgcn_set_split3_fwd(0)
+            assert float((y0 - y1).abs().max()) <= 2e-6 * float(y0.abs().max())
+            assert float((p0.sum(2) - p1.sum(2)).abs().max()) <= 2e-6 * float(p0.sum(2).abs().max())
+    finally:
+        lib.tamgcn_set_split3_fwd(0)
+        lib.tamgcn_set_split_mode(prev)

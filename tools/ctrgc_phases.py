@@ -21,14 +21,15 @@ r = lambda *s: torch.randn(*s, device=dev)
 x = r(N, Cin, T, V); pq = r(S_ * 2 * R, N, V)
 W3 = r(S_ * Cout, Cin) * 0.1; B3 = r(S_ * Cout); W4 = r(S_, Cout, R) * 0.1; B4 = r(S_, Cout)
 A = r(S_, V, V) * 0.1; al = torch.tensor([0.5], device=dev)
-f = lambda: ops.ctrgc_fwd(S(x), pq, W3, B3, W4, B4, A, al, Cin, Cout, S_, R, stats=True, keep_x3=True)
+E = ops.ctrgc_build_E(S(x), pq, W3, B3, W4, B4, A, al, Cin, Cout, S_, R)       # the training configuration: E once per layer in HBM
+f = lambda: ops.ctrgc_fwd(S(x), pq, W3, B3, W4, B4, A, al, Cin, Cout, S_, R, stats=True, keep_x3=True, E=E)
 f(); torch.cuda.synchronize()
 lib.tamgcn_trace_read_ctrgc(buf, 1)
 for _ in range(3):
     f()
 torch.cuda.synchronize()
 lib.tamgcn_trace_read_ctrgc(buf, 1)
-names = ['build_E', 'x3 GEMM chunk (stage + MFMA + tile write)', 'aggregate + z -> LDS', 'barrier', 'copy-out (y, x3) + stats']
+names = ['load / build E', 'x3 GEMM chunk (stage + MFMA + tile write)', 'aggregate + z -> LDS', 'barrier', 'copy-out (y, x3) + stats']
 nb = buf[9] or 1
 print(f'ctrgc_fwd Cin={Cin} Cout={Cout} T={T}: workgroups traced {nb}; shader clocks per workgroup (wave 0):')
 for i, nm in enumerate(names):
