@@ -805,7 +805,7 @@ class CrossEntropyLoss(torch.nn.Module):
             raise RuntimeError('tam_gcn_amd.CrossEntropyLoss: expected (N, K) fp32 logits and (N,) int64 class indices')
         if not logits.is_cuda:
             raise RuntimeError('tam_gcn_amd: the loss runs on MI355X only (got a CPU tensor); there is no CPU fallback')
-        return CrossEntropyFn.run(logits, labels)
+        return torch.ops.tamgcn.cross_entropy(logits, labels)[0]        # tam_gcn_amd.torch_ops
 
 
 # ===========================================================================
@@ -941,3 +941,6 @@ class PointwiseConvFn(_Fn):
         if ctx.needs_input_grad[0]:
             dx, _ = ops.conv(S(dy), K=M, w=w.reshape(M, K), bias=None, M=K, wmode=1)
         return dx, dw, db
+
+
+from . import torch_ops  # noqa: E402,F401  (registers torch.ops.tamgcn.*; imports only .ops)

@@ -22,6 +22,7 @@ import torch
 import torch.nn as nn
 
 from .. import functional as Fn
+from .. import torch_ops  # noqa: F401  (registers torch.ops.tamgcn.*)
 
 
 def import_class(name):
@@ -285,7 +286,7 @@ class CTRGC(nn.Module):
             A = torch.zeros(V, V, device=x.device)
         if not isinstance(alpha, torch.Tensor):
             alpha = torch.tensor([float(alpha)], device=x.device)
-        return Fn.CTRGCFn.run(x, A, alpha, *self._tensors())
+        return torch.ops.tamgcn.ctrgc(x, A, alpha, *self._tensors())
 
 
 # ---------------------------------------------------------------------------
@@ -473,7 +474,7 @@ class Model(nn.Module):
         if isinstance(self.drop_out, nn.Dropout):          # drop_out > 0: pool here, torch's dropout + linear (reference :343-348)
             x = x.view(N, M, x.size(1), -1).mean(3).mean(1)
             return self.fc(self.drop_out(x))
-        return Fn.HeadFn.run(x, self.fc.weight, self.fc.bias, M)
+        return torch.ops.tamgcn.head(x, self.fc.weight, self.fc.bias, M)
 
     def extract_feature(self, x):
         x, N, M = self._blocks(_require_hip(x))

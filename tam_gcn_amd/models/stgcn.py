@@ -131,13 +131,13 @@ class Model(nn.Module):
             x = x.view(N, M, x.size(1), -1).mean(3).mean(1)
             x = self.drop_out(x)
             return torch.nn.functional.linear(x, self.fcn.weight.view(self.fcn.weight.size(0), -1), self.fcn.bias)
-        return Fn.HeadFn.run(x, self.fcn.weight.view(self.fcn.weight.size(0), -1), self.fcn.bias, M)   # :193-198
+        return torch.ops.tamgcn.head(x, self.fcn.weight.view(self.fcn.weight.size(0), -1), self.fcn.bias, M)   # :193-198
 
     def extract_feature(self, x):
         x, N, M = self._blocks(_require_hip(x))
         _, c, t, v = x.size()
         feature = x.view(N, M, c, t, v).permute(0, 2, 3, 4, 1)
-        o = Fn.PointwiseConvFn.run(x, self.fcn.weight, self.fcn.bias)
+        o = torch.ops.tamgcn.pointwise_conv(x, self.fcn.weight, self.fcn.bias)
         output = o.view(N, M, -1, t, v).permute(0, 2, 3, 4, 1)
         return output, feature
 

@@ -1,0 +1,68 @@
+"""-m gpu: the torch.library registration (tam_gcn_amd/torch_ops.py): schema / fake-tensor / autograd-registration checks by
+torch.library.opcheck, tracing without a graph break (torch.compile, fullgraph), and equality with the autograd.Function
+forms the registered ops replaced."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from params import make_input, make_labels            # noqa: E402
+from tam_gcn_amd import functional as Fn, torch_ops    # noqa: E402,F401
+from tam_gcn_amd.models import ctrgcn as M             # noqa: E402
+
+
+def _ctrgc_args(dev, V=20, Cin=64, Cout=64, R=8, N=2, T=8):
+    g = torch.Generator().manual_seed(1)
+    r = lambda *s: (torch.rand(*s, generator=g) * 2 - 1).to(dev)        # noqa: E731
+    return [r(N, Cin, T, V), r(V, V) * 0.2, torch.tensor([0.6], device=dev), r(R, Cin, 1, 1) * 0.2, r(R) * 0.1, r(R, Cin, 1, 1) * 0.2,
+            r(R) * 0.1, r(Cout, Cin, 1, 1) * 0.2, r(Cout) * 0.1, r(Cout, R, 1, 1) * 0.3, r(Cout) * 0.1]
+
+
+def test_opcheck_and_registration():
+    dev = torch.device('cuda:0')
+    args = _ctrgc_args(dev)
+    for t in args:
+        t.requires_grad_(t.is_floating_point())
+    utils = ('test_schema', 'test_faketensor', 'test_autograd_registration')
+    torch.library.opcheck(torch.ops.tamgcn.ctrgc.default, tuple(args), test_utils=utils)
+    logits = make_input((7, 10), 3).to(dev).requires_grad_(True)
+    torch.library.opcheck(torch.ops.tamgcn.cross_entropy.default, (logits, make_labels(7, 10, 4).to(dev)), test_utils=utils)
+    x = make_input((2, 32, 6, 20), 5).to(dev).requires_grad_(True)
+    w, b = make_input((4, 32, 1, 1), 6).to(dev).requires_grad_(True), make_input((4,), 7).to(dev).requires_grad_(True)
+    torch.library.opcheck(torch.ops.tamgcn.pointwise_conv.default, (x, w, b), test_utils=utils)
+    W, bb = make_input((10, 32), 8).to(dev).requires_grad_(True), make_input((10,), 9).to(dev).requires_grad_(True)
+    torch.library.opcheck(torch.ops.tamgcn.head.default, (x, W, bb, 1), test_utils=utils)
+    parent = torch.arange(20, dtype=torch.int32, device=dev).roll(1)
+    torch.library.opcheck(torch.ops.tamgcn.stream_derive.default, (make_input((2, 3, 8, 20, 1), 2).to(dev), parent, 1),
+                          test_utils=('test_schema', 'test_faketensor'))
+
+
+def test_registered_ops_equal_the_function_forms_and_trace_without_graph_break():
+    dev = torch.device('cuda:0')
+    args = _ctrgc_args(dev)
+    a1 = [t.clone().requires_grad_(t.is_floating_point()) for t in args]
+    a2 = [t.clone().requires_grad_(t.is_floating_point()) for t in args]
+    y1 = torch.ops.tamgcn.ctrgc(*a1)
+    y2 = Fn.CTRGCFn.run(*a2)
+    cot = make_input(tuple(y1.shape), 11).to(dev)
+    (y1 * cot).sum().backward()
+    (y2 * cot).sum().backward()
+    assert torch.equal(y1, y2)
+    for u, v in zip(a1, a2):
+        assert torch.allclose(u.grad, v.grad, rtol=1e-5, atol=1e-7)
+
+    mod = M.CTRGC(64, 64).to(dev)
+    ce = Fn.CrossEntropyLoss()
+
+    def f(x, A, alpha, lab):
+        y = mod(x, A, alpha)                                       # torch.ops.tamgcn.ctrgc
+        logits = torch.ops.tamgcn.head(y, mod.conv3.weight.view(64, 64)[:10].contiguous(), mod.conv3.bias[:10].contiguous(), 1)
+        return ce(logits, lab)                                     # torch.ops.tamgcn.cross_entropy
+
+    x, A, alpha = args[0].clone().requires_grad_(True), args[1].clone(), args[2].clone()
+    lab = make_labels(2, 10, 4).to(dev)
+    eager = f(x, A, alpha, lab)
+    compiled = torch.compile(f, backend='eager', fullgraph=True)(x, A, alpha, lab)     # fullgraph: any graph break raises
+    assert torch.allclose(eager, compiled)
+    compiled.backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all()
