@@ -72,7 +72,8 @@ class _Probe:
         fn = getattr(self._lib, name)
         if not name.startswith('tamgcn_') or name in ('tamgcn_last_error', 'tamgcn_last_kernel', 'tamgcn_version', 'tamgcn_conv_nparts',
                                                      'tamgcn_ew_nparts', 'tamgcn_ctrgc_lds_bytes', 'tamgcn_get_split_mode',
-                                                     'tamgcn_set_split_mode', 'tamgcn_wgrad_max_split'):
+                                                     'tamgcn_set_split_mode', 'tamgcn_wgrad_max_split', 'tamgcn_ctrgc_tiled_supported',
+                                                     'tamgcn_ctrgc_tiled_chunks', 'tamgcn_set_split3_fwd'):
             return fn
 
         def wrapped(*args):

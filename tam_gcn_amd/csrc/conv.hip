@@ -813,17 +813,20 @@ __global__ __launch_bounds__(G_NT, 2) void conv1x1_glds_kernel(const ConvArgs a,
 //   fragment  lane (j, kq) owns k = 4e + kq, e = 0..7: ONE K = 32 step per chunk; B of a column tile is split once and
 //             meets the four row tiles' pre-split A fragments
 // ===========================================================================
-constexpr int GS_BK = 32, GS_BMT = 128, GS_MT = 4, GS_NST = 2;
+constexpr int GS_BK = 32, GS_NST = 2;
 
 // TERMS = 2: the two-term split (backward: weight view w[k][m], wmode 1);  TERMS = 3, WM0: the three-term split for the
 // FORWARD 1x1 convolutions into >= 128 channels (weight rows w[m][k]), fp32-exact to rounding, with BatchNorm moments.
-template <int TERMS, bool WM0>
+// MT = row tiles per wave: 4 -> 128-row workgroup tile (layers into >= 128 channels), 2 -> 64 rows (the C = 64 layers' data gradients).
+template <int TERMS, bool WM0, int MT>
 __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs a, int ntt, int nmt) {
+    constexpr int GS_MT = MT, GS_BMT = 32 * MT, WROWS = 16 * MT;   // rows of the workgroup tile / of one wave row-group
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int BK = GS_BK;
     constexpr int STG = BK * G_PBMAX + BK * GS_BMT;               // floats per stage
     constexpr int MAXB = ((BK / 4) * 5 + 7) / 8;                  // B pieces per wave and chunk
-    constexpr int NAP = BK * GS_BMT / 256 / 8;                    // A pieces per wave and chunk (2)
+    constexpr int NAP = BK * GS_BMT / 256 / 8;                    // A pieces per wave and chunk (2 at 128 rows, 1 at 64)
+    constexpr int QR = GS_BMT / 4, RPP = 64 / QR;                 // w[k][m] image: channel quads per k row, k rows per piece
     float* cf = smem + GS_NST * STG;                              // [3][K]
     float* Ss = cf + 3 * a.K;                                     // [2][4*BM] row moments
     float* Bc = Ss + 2 * 4 * BM;                                  // [128] per-row constant of the linear prologue
@@ -892,7 +895,7 @@ __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs
             a_ok[i] = m0 + m < a.M;
             a_rel[i] = (m0 + (a_ok[i] ? m : 0)) * (int)a.ws_m + 4 * (q ^ (m & 7));
         } else {
-            const int kr = piece * 2 + (lane >> 5), q = lane & 31;    // k row in the chunk, physical channel quad
+            const int kr = piece * RPP + lane / QR, q = lane % QR;    // k row in the chunk, physical channel quad
             const int qs = q ^ ((kr & 1) << 2);                       // source quad: rows of different parity sit 16 banks apart
             a_ok[i] = m0 + qs * 4 < a.M;                              // M % 4 == 0 (host)
             a_rel[i] = kr * (int)a.ws_k + (m0 + qs * 4) * (int)a.ws_m;
@@ -927,7 +930,7 @@ __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs
     int aoff[GS_MT];                                               // channel of row tile mt, swizzled for this lane's k parity
 #pragma unroll
     for (int mt = 0; mt < GS_MT; ++mt) {
-        const int m = wm * 64 + mt * 16 + j;
+        const int m = wm * WROWS + mt * 16 + j;
         aoff[mt] = WM0 ? m : (((m >> 2) ^ ((kq & 1) << 2)) << 2) + (m & 3);
     }
     f32x4 acc[GS_MT][G_CWT];
@@ -935,7 +938,9 @@ __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs
     for (int mt = 0; mt < GS_MT; ++mt)
 #pragma unroll
         for (int c = 0; c < G_CWT; ++c) acc[mt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float bsum[GS_MT] = {0.f, 0.f, 0.f, 0.f};                     // this lane's share of (W^T c0)[m]
+    float bsum[GS_MT];                                            // this lane's share of (W^T c0)[m]
+#pragma unroll
+    for (int mt = 0; mt < GS_MT; ++mt) bsum[mt] = 0.f;
 
     __syncthreads();
     const int nch = nsrc * nchk;
@@ -1005,12 +1010,12 @@ __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs
     for (int mt = 0; mt < GS_MT; ++mt) {
         float t = bsum[mt];
         t += __shfl_xor(t, 16); t += __shfl_xor(t, 32);
-        if (wn == 0 && kq == 0) Bc[wm * 64 + mt * 16 + j] = t;
+        if (wn == 0 && kq == 0) Bc[wm * WROWS + mt * 16 + j] = t;
     }
     for (int r0 = 0; r0 < GS_BMT; r0 += RP) {
         __syncthreads();
-        if (wm * 64 <= r0 && r0 < wm * 64 + 64) {
-            const int mtb = (r0 - wm * 64) / 16;                  // this pass = row tiles mtb, mtb+1 of the wave
+        if (wm * WROWS <= r0 && r0 < wm * WROWS + WROWS) {
+            const int mtb = (r0 - wm * WROWS) / 16;               // this pass = row tiles mtb, mtb+1 of the wave
 #pragma unroll
             for (int mt2 = 0; mt2 < 2; ++mt2)
 #pragma unroll
@@ -1018,7 +1023,7 @@ __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs
                     const int col = (wn * G_CWT + c) * 16 + j;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const f32x4 v = mtb == 0 ? acc[mt2][c] : acc[2 + mt2][c];
+                        const f32x4 v = (MT == 2 || mtb == 0) ? acc[mt2][c] : acc[(MT == 2 ? 0 : 2) + mt2][c];
                         Tt[(mt2 * 16 + kq * 4 + r) * PT + col] = v[r] + Bc[r0 + mt2 * 16 + kq * 4 + r];
                     }
                 }
@@ -1147,26 +1152,33 @@ extern "C" int tamgcn_conv(const tamgcn_conv_desc* d, void* stream) {
     const bool aligned16 = (((uintptr_t)d->src.x1 | (uintptr_t)(d->src.x2 ? d->src.x2 : d->src.x1) | (uintptr_t)d->w) & 15) == 0;
     const bool glds = p.vec && p.flat && d->K % 16 == 0 && p.LB >= 64 && p.LB <= G_PBMAX && (p.LB & 3) == 0 &&
                       aligned16 && (long long)d->K * d->T_in * d->V < (1LL << 30);
-    // 128-row tiles on the bf16 matrix cores, operands split in registers (linear prologue only: it folds into the weights):
-    //   backward (w[k][m]): two-term split, no moments;  forward (w[m][k]): three-term split (fp32-exact), with moments.
-    const size_t lds_split = sizeof(float) * ((size_t)GS_NST * (GS_BK * G_PBMAX + GS_BK * GS_BMT) + 3 * (size_t)d->K + 2 * 4 * BM + GS_BMT);
-    const bool big_ok = glds && tamgcn_split_mode() >= 1 && d->src.act == 0 && d->M >= 128 && d->M % 4 == 0 && d->K % GS_BK == 0 &&
+    // tiles on the bf16 matrix cores, operands split in registers (linear prologue only: it folds into the weights):
+    //   backward (w[k][m]): two-term split, no moments, 128-row tiles into >= 128 channels, 64-row tiles into 64;
+    //   forward (w[m][k], opt-in): three-term split (fp32-exact), with moments, 128-row tiles.
+    const int bmt = d->M >= 128 ? 128 : 64;
+    const size_t lds_split = sizeof(float) * ((size_t)GS_NST * (GS_BK * G_PBMAX + GS_BK * bmt) + 3 * (size_t)d->K + 2 * 4 * BM + bmt);
+    const bool big_ok = glds && tamgcn_split_mode() >= 1 && d->src.act == 0 && d->M >= 64 && d->M % 4 == 0 && d->K % GS_BK == 0 &&
                         lds_split <= 160 * 1024 && !d->post_coef;
-    const bool big = big_ok && d->wmode == 1 && !d->stats_part;
-    const bool big3 = big_ok && d->wmode == 0 && tamgcn_split3_fwd();
+    const bool big = big_ok && d->wmode == 1 && !d->stats_part && (d->M >= 128 || tamgcn_split64());
+    const bool big3 = big_ok && d->wmode == 0 && d->M >= 128 && tamgcn_split3_fwd();
     if (big || big3) {
-        const int nmt = ceil_div(d->M, GS_BMT);
+        const int nmt = ceil_div(d->M, bmt);
         const unsigned nblk = (unsigned)(d->N * p.ntt * nmt);
         if (big3) {
             static tg_devmask f3 = 0;
-            tg_allow_lds((const void*)conv1x1_glds_split_kernel<3, true>, 160 * 1024, &f3);
-            hipLaunchKernelGGL((conv1x1_glds_split_kernel<3, true>), dim3(nblk), dim3(G_NT), lds_split, (hipStream_t)stream, a, p.ntt, nmt);
+            tg_allow_lds((const void*)conv1x1_glds_split_kernel<3, true, 4>, 160 * 1024, &f3);
+            hipLaunchKernelGGL((conv1x1_glds_split_kernel<3, true, 4>), dim3(nblk), dim3(G_NT), lds_split, (hipStream_t)stream, a, p.ntt, nmt);
             tamgcn_note_kernel("conv1x1_glds_split_kernel<3, fwd>");
-        } else {
+        } else if (bmt == 128) {
             static tg_devmask fs = 0;
-            tg_allow_lds((const void*)conv1x1_glds_split_kernel<2, false>, 160 * 1024, &fs);
-            hipLaunchKernelGGL((conv1x1_glds_split_kernel<2, false>), dim3(nblk), dim3(G_NT), lds_split, (hipStream_t)stream, a, p.ntt, nmt);
+            tg_allow_lds((const void*)conv1x1_glds_split_kernel<2, false, 4>, 160 * 1024, &fs);
+            hipLaunchKernelGGL((conv1x1_glds_split_kernel<2, false, 4>), dim3(nblk), dim3(G_NT), lds_split, (hipStream_t)stream, a, p.ntt, nmt);
             tamgcn_note_kernel("conv1x1_glds_split_kernel");
+        } else {
+            static tg_devmask f6 = 0;
+            tg_allow_lds((const void*)conv1x1_glds_split_kernel<2, false, 2>, 160 * 1024, &f6);
+            hipLaunchKernelGGL((conv1x1_glds_split_kernel<2, false, 2>), dim3(nblk), dim3(G_NT), lds_split, (hipStream_t)stream, a, p.ntt, nmt);
+            tamgcn_note_kernel("conv1x1_glds_split_kernel<2, bwd, 64 rows>");
         }
     } else if (glds) {
         const int nmt = ceil_div(d->M, G_BMT);

@@ -265,8 +265,10 @@ __global__ __launch_bounds__(EW_THREADS) void maxpool_bwd_kernel(RowGeo geo, Src
 }
 
 // ---- residual add (+ReLU) -------------------------------------------------
+// rowmean != nullptr: also the mean of every output row (the last block's contribution to the model head's pooling,
+// models/ctrgcn.py:343-345, taken while the row is in registers)
 __global__ __launch_bounds__(EW_THREADS) void add_act_fwd_kernel(RowGeo geo, SrcDev a, SrcDev res, int has_res, int relu,
-                                                                 int C, int L, float* out) {
+                                                                 int C, int L, float* out, float* rowmean) {
     int c, n, li;
     const bool rowok = row_coords(geo, C, c, n, li);
     if (!rowok) L = 0;                     // idle lanes only take part in the shuffles
@@ -274,19 +276,28 @@ __global__ __launch_bounds__(EW_THREADS) void add_act_fwd_kernel(RowGeo geo, Src
     RowSrc rr = ra;
     if (has_res) rr = row_src(res, ((long long)n * res.ctot + res.coff + c) * L, res.coff + c);
     float* op = out + ((long long)n * C + c) * L;
+    const int Lrow = L;
+    float acc = 0.f;
     if (EW_VEC(L)) {
         for (int i = li; i < (L >> 2); i += geo.tpr) {
             float4 v = row_val4(ra, i);
             if (has_res) { float4 r = row_val4(rr, i); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
             if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             reinterpret_cast<float4*>(op)[i] = v;
+            acc += (v.x + v.y) + (v.z + v.w);
         }
     } else {
         for (int i = li; i < L; i += geo.tpr) {
             float v = row_val(ra, i);
             if (has_res) v += row_val(rr, i);
-            op[i] = relu ? fmaxf(v, 0.f) : v;
+            v = relu ? fmaxf(v, 0.f) : v;
+            op[i] = v;
+            acc += v;
         }
+    }
+    if (rowmean) {                          // uniform over the launch: every lane of the wave reaches the shuffles
+        for (int o = 1; o < geo.tpr; o <<= 1) acc += __shfl_xor(acc, o);
+        if (li == 0 && rowok) rowmean[(long long)n * C + c] = acc / (float)Lrow;
     }
 }
 
@@ -447,11 +458,11 @@ extern "C" int tamgcn_maxpool_bwd(const tamgcn_src* gy, const tamgcn_src* src, c
 }
 
 extern "C" int tamgcn_add_act_fwd(const tamgcn_src* a, const tamgcn_src* res, int relu,
-                                  int N, int C, int T, int V, float* out, void* stream) {
+                                  int N, int C, int T, int V, float* out, float* rowmean, void* stream) {
     TG_CHECK(a && a->x1 && out && grid_ok(N, C), "tamgcn_add_act_fwd: bad args");
     const RowGeo geo = row_geo(N, C, T * V, true);
     hipLaunchKernelGGL(add_act_fwd_kernel, row_grid(geo), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                       geo, make_src(*a), res ? make_src(*res) : null_src(), res ? 1 : 0, relu, C, T * V, out);
+                       geo, make_src(*a), res ? make_src(*res) : null_src(), res ? 1 : 0, relu, C, T * V, out, rowmean);
     tamgcn_note_kernel("add_act_fwd_kernel");
     TG_LAUNCH_CHECK("tamgcn_add_act_fwd");
     return 0;

@@ -43,6 +43,14 @@ int tamgcn_split_mode(void) {
 // (TAMGCN_SPLIT3_FWD=1, with split mode >= 1).  Measured r02: 11 % on those GEMMs (config 4: 151 -> 149 ms / step, N-UCLA
 // and NTU steps unchanged) -- the 128-row split kernels are bound by the operand splitting and their two-stage DMA ring, not
 // by the matrix pipe -- while its 2-8x fp32 rounding noise moves more ReLU masks in the 4-clip SGD fixtures: not the default.
+// two-term split data-gradient GEMMs also for the 64-channel layers (64-row tiles): opt-in (TAMGCN_SPLIT64=1).  Measured r02: the
+// 2.18 ms of exact kernels it replaces become 2.31 ms -- those launches are bound by their prologue / epilogue latency, not by the matrix pipe.
+int tamgcn_split64(void) {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("TAMGCN_SPLIT64"); v = e ? (atoi(e) != 0) : 0; }
+    return v;
+}
+
 static int g_split3 = -1;
 int tamgcn_split3_fwd(void) {
     if (g_split3 < 0) { const char* e = getenv("TAMGCN_SPLIT3_FWD"); g_split3 = e ? (atoi(e) != 0) : 0; }

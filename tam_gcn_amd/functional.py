@@ -335,9 +335,12 @@ def _tpad(k, d):
     return (k + (k - 1) * (d - 1) - 1) // 2
 
 
-def tcn_forward(g, P, training, save, xres=None):
+def tcn_forward(g, P, training, save, xres=None, pool=None):
     """g (N,Cin,T,V) -> (N,Cout,T2,V).  xres: tensor the residual branch reads
-    (defaults to g, as in MultiScale_TemporalConv; TCN_GCN_unit passes the block input)."""
+    (defaults to g, as in MultiScale_TemporalConv; TCN_GCN_unit passes the block input).
+    pool: None | list -- the final pass appends the (N, Cout) means over (t, v) of its output (the model head's
+    pooling input, models/ctrgcn.py:343-345); left empty by the launch-fused eval path, whose output has no single
+    final pass."""
     N, Cin, T, V = g.shape
     Cb, nb, s = P.Cb, P.nb, P.stride
     Cout = P.Cout
@@ -389,7 +392,11 @@ def tcn_forward(g, P, training, save, xres=None):
         res = None
     fk.__exit__()                                      # join all branches
     bo.flush()
-    out = ops.add_act_fwd(S(cat_pre, coef=coef_c), res, P.relu, Cout)
+    if pool is not None:
+        out, rm = ops.add_act_fwd(S(cat_pre, coef=coef_c), res, P.relu, Cout, rowmean=True)
+        pool.append(rm)
+    else:
+        out = ops.add_act_fwd(S(cat_pre, coef=coef_c), res, P.relu, Cout)
     sv = None
     if save:
         sv = dict(g=g, xres=xres, h_pre=h_pre, cat_pre=cat_pre, r_pre=r_pre, out=out, coef_h=coef_h, save_h=save_h,
@@ -613,24 +620,32 @@ class TCNGCNUnitFn(_Fn):
     """relu(tcn1(gcn1(x)) + residual(x)) as one autograd node (models/ctrgcn.py:282-284)."""
 
     @staticmethod
-    def forward(ctx, mod, x, ngcn, *params):
+    def forward(ctx, mod, x, ngcn, emit, *params):
+        """emit: also return the (N, Cout) row means of the output (non-differentiable side output: the model head's
+        pooling input; its gradient reaches the block through `out`).  Empty (0, Cout) when the pass that would
+        produce it did not run (launch-fused eval path)."""
         Pg = mod.gcn1._pack(params[:ngcn])
         Pt = mod._pack_tcn(params[ngcn:])
         save = _needs(ctx)
         training = mod.training
         g, svg = gcn_forward(x, Pg, training, save)
-        out, svt = tcn_forward(g, Pt, training, save, xres=x)
+        pool = [] if emit else None
+        out, svt = tcn_forward(g, Pt, training, save, xres=x, pool=pool)
         ctx.mod, ctx.Pg, ctx.Pt, ctx.svg, ctx.svt, ctx.ngcn = mod, Pg, Pt, svg, svt, ngcn
-        return out
+        if not emit:
+            return out
+        rm = pool[0] if pool else out.new_empty(0, out.shape[1])
+        ctx.mark_non_differentiable(rm)
+        return out, rm
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, _drm=None):
         need_dx = ctx.needs_input_grad[1]
         dg, dxres, Gt = tcn_backward(ctx.Pt, ctx.svt, dout.contiguous(), need_dg=True, need_dxres=need_dx)
         ctx.svt = None
         dx, Gg = gcn_backward(ctx.Pg, ctx.svg, dg, need_dx=need_dx, extra_dx=dxres)
         ctx.svg = None
-        return (None, dx, None) + tuple(ctx.mod.gcn1._route(Gg)) + tuple(ctx.mod._route_tcn(Gt))
+        return (None, dx, None, None) + tuple(ctx.mod.gcn1._route(Gg)) + tuple(ctx.mod._route_tcn(Gt))
 
 
 # ---------------------------------------------------------------------------

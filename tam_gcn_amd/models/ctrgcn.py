@@ -425,14 +425,17 @@ class TCN_GCN_unit(nn.Module):
     def _route_tcn(self, G):
         return self.tcn1._route(G, ext_conv=self._rmode == 'conv')
 
-    def forward(self, x):
+    def forward(self, x, emit_pool=False):
+        """emit_pool (not in the reference's signature; Model uses it for l10): return (out, rowmean) with rowmean
+        the (N, C) means over (t, v) of out, taken in the block's last pass -- or an empty tensor if that pass did not
+        run (launch-fused eval)."""
         x = _require_hip(x)
         gt = self.gcn1._tensors(x.device)
         tt = self.tcn1._tensors()
         if self._rmode == 'conv':
             r = self.residual
             tt = tt + [r.conv.weight, r.conv.bias, r.bn.weight, r.bn.bias]
-        return Fn.TCNGCNUnitFn.run(self, x, len(gt), *gt, *tt)
+        return Fn.TCNGCNUnitFn.run(self, x, len(gt), bool(emit_pool), *gt, *tt)
 
 
 # ---------------------------------------------------------------------------
@@ -458,22 +461,29 @@ class Model(nn.Module):
         bn_init(self.data_bn, 1)
         self.drop_out = nn.Dropout(drop_out) if drop_out else (lambda x: x)
 
-    def _blocks(self, x):
+    def _blocks(self, x, emit_pool=False):
         if x.dim() == 3:                                   # (N, T, V*C) form, reference :325-327
             N, T, VC = x.shape
             x = x.view(N, T, self.num_point, -1).permute(0, 3, 1, 2).contiguous().unsqueeze(-1)
         N, C, T, V, M = x.size()
         # reference :330-332 (permute, BatchNorm1d, permute back) as one statistics pass + one apply-and-permute pass
         x = Fn.StemFn.run(self.data_bn, x, self.data_bn.weight, self.data_bn.bias)
-        for i in range(1, 11):
+        for i in range(1, 10):
             x = getattr(self, f'l{i}')(x)
-        return x, N, M
+        if emit_pool:
+            x, rm = self.l10(x, emit_pool=True)
+            return x, N, M, rm
+        return self.l10(x), N, M
 
     def forward(self, x):
-        x, N, M = self._blocks(_require_hip(x))
+        x = _require_hip(x)
         if isinstance(self.drop_out, nn.Dropout):          # drop_out > 0: pool here, torch's dropout + linear (reference :343-348)
+            x, N, M = self._blocks(x)
             x = x.view(N, M, x.size(1), -1).mean(3).mean(1)
             return self.fc(self.drop_out(x))
+        x, N, M, rm = self._blocks(x, emit_pool=True)
+        if rm.shape[0]:                                    # l10's last pass already reduced its rows: no second pass over x
+            return torch.ops.tamgcn.head_pooled(x, rm, self.fc.weight, self.fc.bias, M)
         return torch.ops.tamgcn.head(x, self.fc.weight, self.fc.bias, M)
 
     def extract_feature(self, x):

@@ -572,14 +572,16 @@ def maxpool_bwd(gy, src, src_save, C_, stride, d, dcoff):
     return part
 
 
-def add_act_fwd(a, res, relu, C_):
+def add_act_fwd(a, res, relu, C_, rowmean=False):
+    """rowmean: also return the (N, C) means over (t, v) of the output (the model head's pooling input)."""
     N, _, T, V = a.x1.shape
     out = empty(N, C_, T, V, like=a.x1)
+    rm = torch.empty(N, C_, device=out.device, dtype=torch.float32) if rowmean else None
     ac = a.c()
     rc = res.c() if res is not None else None
     _lib.check(_lib_().tamgcn_add_act_fwd(C.byref(ac), C.byref(rc) if rc is not None else None, int(relu),
-                                          N, C_, T, V, _ptr(out), _stream()), 'tamgcn_add_act_fwd')
-    return out
+                                          N, C_, T, V, _ptr(out), _ptr(rm), _stream()), 'tamgcn_add_act_fwd')
+    return (out, rm) if rowmean else out
 
 
 def add_act_bwd(dout, out, relu, a_pre, a_save, r_pre, r_save, want_dz):

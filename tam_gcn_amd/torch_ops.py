@@ -9,6 +9,7 @@ backward is itself a registered op:
     tamgcn::cross_entropy(logits, labels) -> (loss, g);  tamgcn::cross_entropy_backward(g, dloss) -> dlogits
     tamgcn::pointwise_conv(x, w, b) -> y;  tamgcn::pointwise_conv_backward(dy, x, w) -> (dx, dw, db)
     tamgcn::head(x, W, b, M) -> logits;  tamgcn::head_backward(dlogits, x, W, M) -> (dx, dW, db)        models/ctrgcn.py:343-348
+    tamgcn::head_pooled(x, rowmean, W, b, M): the same with the row means of x already taken by the producer of x
     tamgcn::stream_derive(x, parent, mode) -> stream            feeder/feeder_nucla_gcn.py:119-127
     tamgcn::feeder_transform(raw, offsets, rot, idx, parent, V, time_steps, center_joint, mode) -> clips   :85-130
 
@@ -210,6 +211,51 @@ def _head_bwd(ctx, dl):
 
 
 head.register_autograd(_head_bwd, setup_context=_head_setup)
+
+
+# the same head when the last block already produced the (N*M, C) row means of x in its final pass: x is an argument only
+# for its gradient (the broadcast of d pooled), it is not read
+def _pooled_of(rowmean, M):
+    rowmean = _c(rowmean)
+    if M == 1:                                           # one body per clip: the row means are the pooled features
+        return rowmean
+    NM, Cc = rowmean.shape
+    return ops.head_pool_fwd(rowmean.view(NM, Cc, 1, 1), M)
+
+
+@torch.library.custom_op('tamgcn::head_pooled', mutates_args=())
+def head_pooled(x: Tensor, rowmean: Tensor, W: Tensor, b: Tensor, M: int) -> Tensor:
+    return ops.head_fc_fwd(_pooled_of(rowmean, M), _c(W), _c(b))
+
+
+@head_pooled.register_fake
+def _(x, rowmean, W, b, M):
+    return x.new_empty(x.shape[0] // M, W.shape[0])
+
+
+@torch.library.custom_op('tamgcn::head_pooled_backward', mutates_args=())
+def head_pooled_backward(dlogits: Tensor, rowmean: Tensor, W: Tensor, M: int, T: int, V: int) -> tuple[Tensor, Tensor, Tensor]:
+    dW, db, dpooled = ops.head_fc_bwd(_c(dlogits), _pooled_of(rowmean, M), _c(W))
+    return ops.head_pool_bwd(dpooled, M, T, V), dW, db
+
+
+@head_pooled_backward.register_fake
+def _(dlogits, rowmean, W, M, T, V):
+    return rowmean.new_empty(rowmean.shape[0], rowmean.shape[1], T, V), torch.empty_like(W), rowmean.new_empty(W.shape[0])
+
+
+def _headp_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[1], inputs[2])
+    ctx.M, ctx.T, ctx.V = inputs[4], inputs[0].shape[2], inputs[0].shape[3]
+
+
+def _headp_bwd(ctx, dl):
+    rm, W = ctx.saved_tensors
+    dx, dW, db = torch.ops.tamgcn.head_pooled_backward(dl, rm, W, ctx.M, ctx.T, ctx.V)
+    return dx, None, dW, db, None
+
+
+head_pooled.register_autograd(_headp_bwd, setup_context=_headp_setup)
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -67,3 +67,29 @@ def test_registered_ops_equal_the_function_forms_and_trace_without_graph_break()
     assert torch.allclose(eager, compiled)
     compiled.backward()
     assert x.grad is not None and torch.isfinite(x.grad).all()
+
+
+def test_head_pooled_equals_head_and_block_row_means():
+    """tamgcn::head_pooled with the row means the last block's final pass emits == tamgcn::head pooling x itself
+    (models/ctrgcn.py:343-348), forward and every gradient; two bodies per clip and one."""
+    from tam_gcn_amd import ops
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(5)
+    for M in (2, 1):
+        N, Cc, T, V, K = 3, 24, 5, 25, 7
+        pre = torch.randn(N * M, Cc, T, V, generator=g).to(dev)
+        W = torch.randn(K, Cc, generator=g).to(dev).requires_grad_(True)
+        b = torch.randn(K, generator=g).to(dev).requires_grad_(True)
+        x, rm = ops.add_act_fwd(ops.S(pre), None, True, Cc, rowmean=True)
+        assert torch.allclose(rm, x.mean((2, 3)), rtol=1e-5, atol=1e-6)
+        assert torch.equal(x, ops.add_act_fwd(ops.S(pre), None, True, Cc))
+        x1 = x.clone().requires_grad_(True)
+        x2 = x.clone().requires_grad_(True)
+        cot = torch.randn(N, K, generator=g).to(dev)
+        y1 = torch.ops.tamgcn.head(x1, W, b, M)
+        g1 = torch.autograd.grad((y1 * cot).sum(), (x1, W, b))
+        y2 = torch.ops.tamgcn.head_pooled(x2, rm, W, b, M)
+        g2 = torch.autograd.grad((y2 * cot).sum(), (x2, W, b))
+        assert torch.allclose(y1, y2, rtol=1e-5, atol=1e-6)
+        for a, c in zip(g1, g2):
+            assert torch.allclose(a, c, rtol=1e-5, atol=1e-6)
