@@ -355,6 +355,14 @@ int tamgcn_head_fc_bwd(const float* dlogits, const float* pooled, const float* W
 int tamgcn_ce_fwd(const float* logits, const long long* labels, int N, int K, float* loss, float* g, void* stream);
 int tamgcn_ce_bwd(const float* g, const float* dloss, int N, int K, float* dlogits, void* stream);
 
+/* ---- score-level ensemble of the evaluation scripts ----
+ * fused (N, K) = sum_s weights[s] * scores[s]  (softmax = 0: reference ensemble/ensemble_resnet_ctrgcn.py:50-54, score_a + alpha * score_b)
+ *             or sum_s weights[s] * softmax_k(scores[s])  (softmax = 1: ensemble/ensemble_ctrgcn_resnet_eval.py:99-106);
+ * pred (N) int64 = first arg max over k (numpy.argmax); class_stats NULL | int32 [K][2] = (correct, total) per true class
+ * (compute_accuracy, ensemble_ctrgcn_resnet_eval.py:217-234), needs labels (N) int64.  scores is [S][N][K] contiguous. */
+int tamgcn_score_fuse(const float* scores, const float* weights, int S, int N, int K, int softmax,
+                      const long long* labels, float* fused, long long* pred, int* class_stats, void* stream);
+
 /* ---- input side: skeleton streams and the feeder's per-sample transform ----------------------
  * _stream_derive  the other three inputs of the 4-stream recipe from a joint batch x (N, C, T, V, M) resident in HBM:
  *                 mode 1 bone        out[.., v, m] = x[.., v, m] - x[.., parent[v], m]   (reference feeder/feeder_nucla_gcn.py:27-28,

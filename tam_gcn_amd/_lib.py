@@ -117,6 +117,7 @@ SIGNATURES = {
     'tamgcn_add_act_fwd': (_i, [_SP, _SP, _i, _i, _i, _i, _i, _p, _p, _p]),
     'tamgcn_add_act_bwd': (_i, [_p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
     'tamgcn_apply': (_i, [_SP, _i, _i, _i, _i, _p, _i, _i, _p]),
+    'tamgcn_score_fuse': (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     'tamgcn_ce_fwd': (_i, [_p, _p, _i, _i, _p, _p, _p]),
     'tamgcn_ce_bwd': (_i, [_p, _p, _i, _i, _p, _p]),
     'tamgcn_stream_derive': (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _p, _p]),

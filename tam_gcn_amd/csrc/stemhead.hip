@@ -143,6 +143,41 @@ __global__ __launch_bounds__(SH_NT) void ce_bwd_kernel(const float* g, const flo
     if (e < total) dlogits[e] = g[e] * (dloss[0] * scale);
 }
 
+// score-level ensemble of the reference's evaluation scripts: fused[n][k] = sum_s w[s] * (softmax_k? scores[s][n][:]) ,
+// pred[n] = first arg max_k (numpy.argmax), per-class (correct, total) counts.  One lane per sample, K is 10..60.
+// Reference: ensemble/ensemble_resnet_ctrgcn.py:50-54 (raw scores), ensemble/ensemble_ctrgcn_resnet_eval.py:99-108, :217-234.
+__global__ __launch_bounds__(SH_NT) void score_fuse_kernel(const float* scores, const float* w, int S, int N, int K, int softmax,
+                                                           const long long* labels, float* fused, long long* pred, int* stats) {
+    const int n = blockIdx.x * SH_NT + threadIdx.x;
+    if (n >= N) return;
+    float* f = fused + (long long)n * K;
+    for (int k = 0; k < K; ++k) f[k] = 0.f;
+    for (int s = 0; s < S; ++s) {
+        const float* x = scores + ((long long)s * N + n) * K;
+        float mx = 0.f, inv = 1.f;
+        if (softmax) {
+            mx = x[0];
+            for (int k = 1; k < K; ++k) mx = fmaxf(mx, x[k]);
+            float den = 0.f;
+            for (int k = 0; k < K; ++k) den += expf(x[k] - mx);
+            inv = 1.f / den;
+        }
+        const float ws = w[s];
+        // separate multiply and add (no fma contraction): numpy evaluates score_a + (alpha * score_b) with both roundings
+        for (int k = 0; k < K; ++k) f[k] = __fadd_rn(f[k], __fmul_rn(ws, softmax ? expf(x[k] - mx) * inv : x[k]));
+    }
+    int best = 0;
+    for (int k = 1; k < K; ++k) if (f[k] > f[best]) best = k;
+    pred[n] = best;
+    if (labels && stats) {
+        const int l = (int)labels[n];
+        if (l >= 0 && l < K) {
+            atomicAdd(&stats[2 * l + 1], 1);
+            if (l == best) atomicAdd(&stats[2 * l], 1);
+        }
+    }
+}
+
 }  // namespace
 
 static bool sh_dims_ok(int N, int C, int T, int V, int M) {
@@ -218,5 +253,19 @@ extern "C" int tamgcn_ce_bwd(const float* g, const float* dloss, int N, int K, f
     hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)ceil_div(total, SH_NT)), dim3(SH_NT), 0, (hipStream_t)stream, g, dloss, total, 1.f / (float)N, dlogits);
     tamgcn_note_kernel("ce_bwd_kernel");
     TG_LAUNCH_CHECK("tamgcn_ce_bwd");
+    return 0;
+}
+
+extern "C" int tamgcn_score_fuse(const float* scores, const float* weights, int S, int N, int K, int softmax,
+                                 const long long* labels, float* fused, long long* pred, int* class_stats, void* stream) {
+    TG_CHECK(scores && weights && fused && pred && S > 0 && N > 0 && K > 0 && (!class_stats || labels), "tamgcn_score_fuse: bad args");
+    if (class_stats) {
+        hipError_t e = hipMemsetAsync(class_stats, 0, sizeof(int) * 2 * K, (hipStream_t)stream);
+        TG_CHECK(e == hipSuccess, "tamgcn_score_fuse: memset failed");
+    }
+    hipLaunchKernelGGL(score_fuse_kernel, dim3((unsigned)ceil_div(N, SH_NT)), dim3(SH_NT), 0, (hipStream_t)stream,
+                       scores, weights, S, N, K, softmax, labels, fused, pred, class_stats);
+    tamgcn_note_kernel("score_fuse_kernel");
+    TG_LAUNCH_CHECK("tamgcn_score_fuse");
     return 0;
 }

@@ -687,6 +687,17 @@ def ce_fwd(logits, labels):
     return loss, g
 
 
+def score_fuse(scores, weights, softmax, labels=None):
+    """scores (S, N, K) f32, weights (S,) f32 -> fused (N, K), pred (N,) int64, class_stats (K, 2) int32 | None."""
+    S_, N, K = scores.shape
+    fused = torch.empty(N, K, device=scores.device, dtype=torch.float32)
+    pred = torch.empty(N, device=scores.device, dtype=torch.int64)
+    stats = torch.empty(K, 2, device=scores.device, dtype=torch.int32) if labels is not None else None
+    _lib.check(_lib_().tamgcn_score_fuse(_ptr(scores), _ptr(weights), S_, N, K, int(bool(softmax)), _ptr(labels), _ptr(fused), _ptr(pred),
+                                         _ptr(stats), _stream()), 'tamgcn_score_fuse')
+    return fused, pred, stats
+
+
 def ce_bwd(g, dloss):
     N, K = g.shape
     dl = torch.empty_like(g)

@@ -56,3 +56,23 @@ def test_split_mode_switch():
     assert lib.tamgcn_set_split_mode(0) == 0 and lib.tamgcn_get_split_mode() == 0
     assert lib.tamgcn_set_split_mode(7) < 0 and b'tamgcn_set_split_mode' in lib.tamgcn_last_error()
     assert lib.tamgcn_set_split_mode(m0) == 0
+
+
+def test_ensemble_oracle_hand_case():
+    """oracle/ensemble_oracle.py on a case small enough to check by hand (the GPU path is compared with it in
+    tests/test_gpu_ensemble.py)."""
+    import numpy as np
+    from oracle import ensemble_oracle as EO
+    names = ['s0', 's1', 's2', 's3']
+    labels = [1, 0, 2, 1]
+    ra = {'s0': np.float32([0, 1, 0]), 's1': np.float32([0, 0, 3]), 's2': np.float32([1, 0, 0])}          # s3 missing
+    rb = {'s0': np.float32([2, 0, 0]), 's1': np.float32([2, 0, 0]), 's2': np.float32([0, 0, 4]), 's3': np.float32([0, 9, 0])}
+    acc, right, total, pred = EO.fuse_raw(ra, rb, 0.25, names, labels)
+    assert (right, total) == (1, 3) and pred == {'s0': 1, 's1': 2, 's2': 0}       # s2: [1, 0, 1] ties -> first maximum
+    acc, right, total, pred = EO.fuse_raw(ra, rb, 1.0, names, labels)
+    assert pred == {'s0': 0, 's1': 2, 's2': 2} and (right, total) == (1, 3)
+    sc = np.float32([[0, 1, 0], [3, 0, 0], [0, 0, 1], [0, 1, 0]])
+    acc, correct, total, cls = EO.compute_accuracy(sc, np.asarray(labels), 4)
+    assert (correct, total) == (4, 4) and cls[1] == (2, 2, 1.0) and cls[3] == (0, 0, 0.0)
+    f = EO.fuse_softmax(sc, sc, 1.0)
+    assert np.allclose(f.sum(1), 2.0, atol=1e-6)
