@@ -1241,6 +1241,7 @@ struct WgradArgs {
     int BT, TIN;      // frames per staged chunk (gy side / x side)
     int PY, PX;       // LDS pitches
     int n_per;        // samples per split
+    int KTG;          // LDS-DMA kernel: temporal taps (1 = 1x1), one window of the contraction axis per tap
 };
 
 __device__ __forceinline__ float wg_apply(float x1, float x2, float c1, float c2, float c0, int act) {
@@ -1503,7 +1504,12 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(const WgradArgs a) {
 //   prologue    per-ROW coefficients (BatchNorm(-backward) apply, two-source combine, ReLU) are lane
 //               constants here (lane = row), applied to the fragment registers
 //   pipeline    3-stage ring, two chunks in flight, counted vmcnt + one raw s_barrier per chunk
-// Requires T*V % 32 == 0 (no zero padding of the contraction axis is possible with masked DMA).
+//   row tails   a row (T*V floats) that is not a multiple of 32 ends in a chunk that is fetched from [len - 32, len) --
+//               no read past the row -- with the elements the previous chunk already covered zeroed in the gy fragment
+//   k x 1       (stride 1, "same" padding) tap kt contracts gy[t] with x[t + kt*dil - pad]: the same GEMM over the
+//               window of frames both sides have, i.e. two row offsets and a shorter row.  Taps are a grid axis
+//               (blockIdx -> (tap, split, tile)); dW is written [m][k][kt].  Offsets are multiples of V floats:
+//               gfx950 takes dword-aligned 16-byte DMA pieces at full rate (tools/probes/unaligned_probe.hip).
 // ===========================================================================
 constexpr int W_PC = 32, W_NST = 3, W_NT = 512;
 
@@ -1517,17 +1523,25 @@ __global__ __launch_bounds__(W_NT, 2) void wgrad_glds_kernel(const WgradArgs a, 
     constexpr int MAXP = (NPIECE + 7) / 8;                        // per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kq = lane >> 4, wr = wave >> 2, wc = wave & 3;
-    int split, tile;
+    int split, tile, tap;
     {
-        const int L = blockIdx.x, nt = ntk * ntm;
+        const int nt = ntk * ntm, per_tap = nt * a.nsplit;
+        int L = blockIdx.x;
+        tap = L / per_tap; L -= tap * per_tap;
         if ((a.nsplit & 7) == 0) { const int xcd = L & 7, i = L >> 3; tile = i % nt; split = (i / nt) * 8 + xcd; }
         else { split = L / nt; tile = L - split * nt; }
     }
     const int k0 = (tile % ntk) * BKW, m0 = (tile / ntk) * BMW;
-    const long long cs = (long long)a.T_out * a.V;               // == T_in * V
-    const int cps = (int)(cs / W_PC);                             // chunks per sample
+    const long long cs = (long long)a.T_out * a.V;               // == T_in * V: channel-row stride of both operands
+    // this tap's window: frames t with 0 <= t < T and 0 <= t + dlt < T
+    const int dlt = a.KTG > 1 ? tap * a.dil - a.pad : 0;
+    const int wlen = (a.T_out - (dlt < 0 ? -dlt : dlt)) * a.V;    // host: >= 2 * W_PC
+    const long long ylo = dlt < 0 ? (long long)(-dlt) * a.V : 0, xlo = dlt > 0 ? (long long)dlt * a.V : 0;
+    const int cpf = wlen / W_PC, ntail = wlen - cpf * W_PC;       // full chunks, elements of the overlapping last one
+    const int cps = cpf + (ntail ? 1 : 0);                        // chunks per sample
     // a split owns a contiguous range of the (n, chunk) sequence: splits may be finer than samples
-    const int c_begin = split * a.n_per, nch = max(0, min(a.N * cps, c_begin + a.n_per) - c_begin);
+    const int n_per = (a.N * cps + a.nsplit - 1) / a.nsplit;
+    const int c_begin = split * n_per, nch = max(0, min(a.N * cps, c_begin + n_per) - c_begin);
 
     // ---- DMA descriptors.  Stage rows: [Y1 | Y2 | X1 | X2]; lane -> (row in piece, physical slot)
     const int pr = lane >> 3, ps = lane & 7;
@@ -1558,8 +1572,9 @@ __global__ __launch_bounds__(W_NT, 2) void wgrad_glds_kernel(const WgradArgs a, 
     auto issue = [&](int c) {
         float* st = smem + (c % NST) * STG;
         const int gc = c_begin + c, nn = gc / cps, pc = gc - nn * cps;
-        const long long oy = (long long)nn * ystep + (long long)pc * W_PC;
-        const long long ox = (long long)nn * xstep + (long long)pc * W_PC;
+        const int po = pc < cpf ? pc * W_PC : wlen - W_PC;        // the row's last, partial chunk: re-fetch the last 32
+        const long long oy = (long long)nn * ystep + ylo + po;
+        const long long ox = (long long)nn * xstep + xlo + po;
 #pragma unroll
         for (int i = 0; i < MAXP; ++i) {
             if (p_on[i]) {
@@ -1642,6 +1657,16 @@ __global__ __launch_bounds__(W_NT, 2) void wgrad_glds_kernel(const WgradArgs a, 
                 bv[b][y] = v;
             }
         }
+        if (ntail && (c_begin + c) % cps == cpf) {               // overlapping last chunk: keep only its last ntail elements
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * (4 * b + kq) + e < W_PC - ntail) {
+#pragma unroll
+                        for (int x = 0; x < WMT; ++x) av[b][x][e] = 0.f;
+                    }
+        }
         if constexpr (SPL) {                // the lane's eight contraction indices of this chunk = one K = 32 fragment
             bf16x8_t ah[WMT], al[WMT], bh[WKT], bl[WKT];
 #pragma unroll
@@ -1663,7 +1688,7 @@ __global__ __launch_bounds__(W_NT, 2) void wgrad_glds_kernel(const WgradArgs a, 
                         for (int x = 0; x < WMT; ++x) acc[x][y] = mfma16(av[b][x][e], bv[b][y][e], acc[x][y]);
         }
     }
-    float* out = a.part + (long long)split * a.M * a.K;
+    float* out = a.part + (long long)split * a.M * a.K * a.KTG + tap;
 #pragma unroll
     for (int x = 0; x < WMT; ++x)
 #pragma unroll
@@ -1672,36 +1697,8 @@ __global__ __launch_bounds__(W_NT, 2) void wgrad_glds_kernel(const WgradArgs a, 
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + (wr * WMT + x) * 16 + kq * 4 + r;
                 const int k = k0 + (wc * WKT + y) * 16 + j;
-                if (m < a.M && k < a.K) out[(long long)m * a.K + k] = acc[x][y][r];
+                if (m < a.M && k < a.K) out[((long long)m * a.K + k) * a.KTG] = acc[x][y][r];
             }
-}
-
-// The contraction elements the LDS-DMA kernel leaves over when a row (T*V floats) is not a multiple of its 32-element
-// chunk (V = 25: 7500 = 234 * 32 + 12): dW_tail[m][k] = sum_n sum_{p >= cps*32} gy(n, m, p) * x(n, k, p), written as
-// one more partial slab.  16 x 16 outputs per workgroup, the <= 31 tail elements of the 32 rows staged per sample.
-__global__ __launch_bounds__(256) void wgrad_tail_kernel(const WgradArgs a, int p0, int ntail, float* out) {
-    __shared__ float Ys[16][32], Xs[16][32];
-    const int tid = threadIdx.x, mi = tid >> 4, ki = tid & 15;
-    const int m0 = blockIdx.y * 16, k0 = blockIdx.x * 16;
-    const long long cs = (long long)a.T_out * a.V;
-    float acc = 0.f;
-    for (int n = 0; n < a.N; ++n) {
-        __syncthreads();
-        for (int e = tid; e < 2 * 16 * ntail; e += 256) {
-            const int which = e / (16 * ntail), r = (e / ntail) & 15, p = e % ntail;
-            const SrcDev& sd = which ? a.src : a.gy;
-            const int ch = (which ? k0 : m0) + r;
-            float v = 0.f;
-            if (ch < (which ? a.K : a.M)) {
-                const int c = sd.coff + ch;
-                v = src_value(sd, ((long long)n * sd.ctot + c) * cs + p0 + p, c);
-            }
-            (which ? Xs : Ys)[r][p] = v;
-        }
-        __syncthreads();
-        for (int p = 0; p < ntail; ++p) acc = fmaf(Ys[mi][p], Xs[ki][p], acc);
-    }
-    if (m0 + mi < a.M && k0 + ki < a.K) out[(long long)(m0 + mi) * a.K + k0 + ki] = acc;
 }
 
 template <int WMT, int WKT, int NY, int NX, bool SPL>
@@ -1713,17 +1710,9 @@ static int launch_wgrad_glds(WgradArgs& a, hipStream_t s) {
     const size_t lds = NST * STAGE;
     static tg_devmask flag = 0;
     tg_allow_lds((const void*)wgrad_glds_kernel<WMT, WKT, NY, NX, SPL, NST>, 160 * 1024, &flag);
-    const long long cs = (long long)a.T_out * a.V;
-    const int cps = (int)(cs / W_PC), ntail = (int)(cs - (long long)cps * W_PC);
-    const int nsplit_all = a.nsplit;
-    if (ntail) a.nsplit = nsplit_all - 1;                         // the last slab belongs to the tail kernel (host checked nsplit >= 2)
-    a.n_per = ceil_div(a.N * cps, a.nsplit);                      // chunks per split
     const int ntk = ceil_div(a.K, BKW), ntm = ceil_div(a.M, BMW);
-    hipLaunchKernelGGL((wgrad_glds_kernel<WMT, WKT, NY, NX, SPL, NST>), dim3((unsigned)(ntk * ntm * a.nsplit)), dim3(W_NT), lds, s, a, ntk, ntm);
-    if (ntail)
-        hipLaunchKernelGGL(wgrad_tail_kernel, dim3(ceil_div(a.K, 16), ceil_div(a.M, 16)), dim3(256), 0, s, a, cps * W_PC, ntail,
-                           a.part + (long long)(nsplit_all - 1) * a.M * a.K);
-    tamgcn_note_kernel("wgrad_glds_kernel<%d, %d, %d, %d, %s, %d>", WMT, WKT, NY, NX, SPL ? "split" : "f32", NST);
+    hipLaunchKernelGGL((wgrad_glds_kernel<WMT, WKT, NY, NX, SPL, NST>), dim3((unsigned)(ntk * ntm * a.nsplit * a.KTG)), dim3(W_NT), lds, s, a, ntk, ntm);
+    tamgcn_note_kernel("wgrad_glds_kernel<%d, %d, %d, %d, %s, %d>%s", WMT, WKT, NY, NX, SPL ? "split" : "f32", NST, a.KTG > 1 ? " taps" : "");
     return 0;
 }
 
@@ -1819,10 +1808,16 @@ static bool wgrad_glds_plan(const tamgcn_wgrad_desc* d, int* wmt, int* wkt) {
     wgrad_tile(d->M, d->K, d->KT, wmt, wkt);
     const bool al16 = (((uintptr_t)d->gy.x1 | (uintptr_t)d->src.x1 | (uintptr_t)(d->gy.x2 ? d->gy.x2 : d->gy.x1) |
                         (uintptr_t)(d->src.x2 ? d->src.x2 : d->src.x1)) & 15) == 0;
-    // rows whose length is not a multiple of the 32-element chunk leave a tail to wgrad_tail_kernel (one more slab)
-    bool glds = d->KT == 1 && d->stride == 1 && d->pad == 0 && d->T_in == d->T_out && al16 &&
-                (long long)d->T_out * d->V >= 2 * W_PC && (((long long)d->T_out * d->V) % W_PC == 0 || d->nsplit != 1);
+    // 1x1, or k x 1 with "same" padding (one window per tap); every window holds at least two 32-element chunks.
+    // The 16-channel temporal branches stay on the register-staged kernels (one 16x16 tile: nothing for 8 waves to share;
+    // measured r02: N-UCLA step 31.1 vs 30.2 ms, NTU 1.33 vs 1.0 ms per launch); TAMGCN_WGRAD_TAPS=2 sends them here too,
+    // =0 disables the tap form.
+    const bool taps = d->KT > 1 && d->pad == d->dil * (d->KT - 1) / 2 && (d->dil * (d->KT - 1)) % 2 == 0 && tamgcn_wgrad_taps() &&
+                      (d->M > 16 || d->K > 16 || tamgcn_wgrad_taps() == 2);
+    bool glds = (taps || (d->KT == 1 && d->pad == 0)) && d->stride == 1 && d->T_in == d->T_out && al16 &&
+                (long long)(d->T_out - d->pad) * d->V >= 2 * W_PC;
     if (!glds) return false;
+    if (d->KT > 1) { *wmt = d->M <= 64 ? 2 : 4; *wkt = d->K <= 64 ? 2 : 4; }      // the 1x1 rule (units of 32)
     // three stages of both operands (every source) must fit the CU's LDS: shrink the tile
     auto fits = [&](int tm, int tk) {
         const size_t rows = (size_t)tm * 32 * (d->gy.x2 ? 2 : 1) + (size_t)tk * 32 * (d->src.x2 ? 2 : 1);
@@ -1830,7 +1825,9 @@ static bool wgrad_glds_plan(const tamgcn_wgrad_desc* d, int* wmt, int* wkt) {
     };
     if (!fits(*wmt, *wkt) && *wmt == 4) *wmt = 2;
     if (!fits(*wmt, *wkt) && *wkt == 4) *wkt = 2;
-    return fits(*wmt, *wkt);
+    if (fits(*wmt, *wkt)) return true;
+    wgrad_tile(d->M, d->K, d->KT, wmt, wkt);
+    return false;
 }
 
 extern "C" int tamgcn_wgrad_max_split(const tamgcn_wgrad_desc* d) {
@@ -1841,7 +1838,7 @@ extern "C" int tamgcn_wgrad_max_split(const tamgcn_wgrad_desc* d) {
         const long long m = (long long)d->N * ((d->T_out + 7) / 8);
         return (int)(m < d->N ? d->N : (m > 65535 ? 65535 : m));
     }
-    const long long chunks = (long long)d->N * (((long long)d->T_out * d->V) / W_PC);
+    const long long chunks = (long long)d->N * (((long long)(d->T_out - d->pad) * d->V) / W_PC);
     const long long m = chunks / 8;                      // at least 8 chunks of 32 per workgroup
     return (int)(m < d->N ? d->N : (m > 65535 ? 65535 : m));
 }
@@ -1860,15 +1857,19 @@ extern "C" int tamgcn_wgrad(const tamgcn_wgrad_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     int rc, wmt, wkt;
     const bool glds = wgrad_glds_plan(d, &wmt, &wkt);
+    a.KTG = glds ? d->KT : 1;
+    if (glds) {              // tile = 64 or 128 per side by the same rule as wgrad_tile (wmt: rows/32, wkt: cols/64)
+        if (wmt == 2 && wkt == 2) rc = launch_wgrad_glds_src<2, 1>(a, s);
+        else if (wmt == 4 && wkt == 2) rc = launch_wgrad_glds_src<4, 1>(a, s);
+        else if (wmt == 2 && wkt == 4) rc = launch_wgrad_glds_src<2, 2>(a, s);
+        else rc = launch_wgrad_glds_src<4, 2>(a, s);
+        if (rc) return rc;
+        TG_LAUNCH_CHECK("tamgcn_wgrad");
+        return 0;
+    }
     switch (d->KT) {
         case 1:
-            if (glds) {      // tile = 64 or 128 per side by the same rule as wgrad_tile (wmt: rows/32, wkt: cols/64)
-                if (wmt == 2 && wkt == 2) rc = launch_wgrad_glds_src<2, 1>(a, s);
-                else if (wmt == 4 && wkt == 2) rc = launch_wgrad_glds_src<4, 1>(a, s);
-                else if (wmt == 2 && wkt == 4) rc = launch_wgrad_glds_src<2, 2>(a, s);
-                else rc = launch_wgrad_glds_src<4, 2>(a, s);
-            }
-            else if (wmt == 2 && wkt == 2) rc = launch_wgrad<1, 2, 2>(a, s);
+            if (wmt == 2 && wkt == 2) rc = launch_wgrad<1, 2, 2>(a, s);
             else if (wmt == 4 && wkt == 2) rc = launch_wgrad<1, 4, 2>(a, s);
             else if (wmt == 2 && wkt == 4) rc = launch_wgrad<1, 2, 4>(a, s);
             else rc = launch_wgrad<1, 4, 4>(a, s);

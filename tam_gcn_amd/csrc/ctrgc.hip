@@ -378,6 +378,11 @@ __device__ void x3_chunk(const CtrgcArgs& a, int n, int c0, int t0, int bt, floa
             }
         }
     };
+    float b3r[ST][4];                                  // fetched here: in flight under the K loop, not exposed after it
+#pragma unroll
+    for (int s = 0; s < ST; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b3r[s][r] = a.b3[s * a.Cout + c0 + kq * 4 + r];
     prefetch(0);
     for (int k0 = 0; k0 < a.Cin; k0 += SBK) {
         __syncthreads();                               // previous users of the region are done
@@ -449,7 +454,7 @@ __device__ void x3_chunk(const CtrgcArgs& a, int n, int c0, int t0, int bt, floa
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 int cl = kq * 4 + r;
-                X3[(s * 16 + cl) * G::PX3 + col] = acc[s][c][r] + a.b3[s * a.Cout + c0 + cl];
+                X3[(s * 16 + cl) * G::PX3 + col] = acc[s][c][r] + b3r[s][r];
             }
         }
     }

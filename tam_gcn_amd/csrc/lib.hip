@@ -45,6 +45,12 @@ int tamgcn_split_mode(void) {
 // by the matrix pipe -- while its 2-8x fp32 rounding noise moves more ReLU masks in the 4-clip SGD fixtures: not the default.
 // two-term split data-gradient GEMMs also for the 64-channel layers (64-row tiles): opt-in (TAMGCN_SPLIT64=1).  Measured r02: the
 // 2.18 ms of exact kernels it replaces become 2.31 ms -- those launches are bound by their prologue / epilogue latency, not by the matrix pipe.
+int tamgcn_wgrad_taps(void) {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("TAMGCN_WGRAD_TAPS"); v = e ? atoi(e) : 1; }
+    return v;
+}
+
 int tamgcn_split64(void) {
     static int v = -1;
     if (v < 0) { const char* e = getenv("TAMGCN_SPLIT64"); v = e ? (atoi(e) != 0) : 0; }

@@ -165,13 +165,14 @@ def wgrad(gy, src, M, K, KT=1, dil=1, stride=1, pad=0, rows=None):
     per_clip = max(gy.x1.shape[1] * T_out * V, src.x1.shape[1] * T_in * V)
     chunks = n_chunks(N, per_clip) if N * per_clip > CHUNK_ELEMS else [(0, N)]
     # same tile rule as wgrad_tile() in csrc/conv.hip: aim at ~4 resident workgroups per CU
-    if KT == 1:
+    taps = KT > 1 and stride == 1 and T_in == T_out and (M > 16 or K > 16)      # one window per tap on the LDS-DMA kernel
+    if KT == 1 or taps:
         bm, bk = (64 if M <= 64 else 128), (64 if K <= 64 else 128)
     elif KT == 9:
         bm = bk = 32
     else:
         bm = bk = 32 if (M <= 32 and K <= 32) else 64
-    tiles = ((M + bm - 1) // bm) * ((K + bk - 1) // bk)
+    tiles = ((M + bm - 1) // bm) * ((K + bk - 1) // bk) * (KT if taps else 1)
     lib = _lib_()
     descs = []
     for n0, n1 in chunks:

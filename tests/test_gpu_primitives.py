@@ -38,6 +38,18 @@ CONV_CASES = [
     (2, 64, 96, 40, 20, 1, 1, 1),      # two 48-row channel tiles, three frame tiles (staged epilogue overshoot)
     (2, 192, 64, 33, 20, 1, 1, 1),     # K = 6 chunks, ragged last frame tile
     (2, 48, 144, 16, 20, 1, 1, 1),
+    # k x 1 weight gradients as tap windows of the LDS-DMA kernel (more than 16 channels, stride 1); rows whose windows
+    # are not multiples of the 32-element chunk (overlapping last chunk), V = 25 (dword-aligned windows), V = 64
+    (3, 32, 32, 16, 20, 5, 1, 1),
+    (3, 64, 64, 16, 20, 5, 2, 1),
+    (2, 64, 32, 13, 20, 5, 2, 1),
+    (2, 64, 64, 11, 25, 5, 1, 1),
+    (2, 32, 64, 9, 25, 5, 2, 1),
+    (1, 64, 64, 12, 64, 5, 2, 1),
+    (2, 40, 24, 14, 20, 3, 1, 1),
+    (2, 24, 24, 10, 20, 9, 1, 1),
+    (2, 64, 64, 5, 25, 5, 2, 1),       # T - pad = 1 frame: too short for a window, stays on the register-staged kernel
+    (2, 48, 80, 7, 25, 1, 1, 1),       # 1x1, rows of 175 = 5 * 32 + 15 floats
 ]
 
 
@@ -408,4 +420,50 @@ def test_three_term_split_forward_gemm_matches_exact_kernels():
             assert float((p0.sum(2) - p1.sum(2)).abs().max()) <= 2e-6 * float(p0.sum(2).abs().max())
     finally:
         lib.tamgcn_set_split3_fwd(0)
+        lib.tamgcn_set_split_mode(prev)
+
+
+@pytest.mark.parametrize('shape', [(3, 64, 64, 16, 20, 5, 1), (2, 32, 64, 13, 25, 5, 2), (2, 64, 48, 10, 64, 5, 2)])
+def test_kx1_weight_gradient_taps_with_prologue(shape, monkeypatch):
+    """k x 1 weight gradient on the LDS-DMA kernel with the operands the temporal branches hand it: gy a two-source
+    BatchNorm-backward apply, x a BatchNorm apply + ReLU, both channel slices of wider tensors; fp64 torch reference.
+    Both arithmetic modes (split-bf16 default, exact fp32)."""
+    from tam_gcn_amd import ops, _lib
+    from tam_gcn_amd.ops import S
+    N, M, K, T, V, KT, dil = shape
+    pad = dil * (KT - 1) // 2
+    d = dev()
+    ap = lambda c, a, b: c[0][None, :, None, None] * a + (c[1][None, :, None, None] * b if b is not None else 0) + c[2][None, :, None, None]
+    Kt, Mt = K + 16, M + 32
+    x1, cx = rnd((N, Kt, T, V), 1), rnd((3, Kt), 3)
+    g1, g2, cg = rnd((N, Mt, T, V), 4), rnd((N, Mt, T, V), 5), rnd((3, Mt), 6)
+    xv = torch.relu(ap(cx.double(), x1.double(), None))[:, 16:16 + K]
+    gv = ap(cg.double(), g1.double(), g2.double())[:, 32:32 + M]
+    w = torch.zeros(M, K, KT, 1, dtype=torch.float64, requires_grad=True)
+    xv = xv.clone().requires_grad_(False)
+    y = F.conv2d(xv, w, None, padding=(pad, 0), dilation=(dil, 1))
+    (y * gv).sum().backward()
+    ref = w.grad
+    t = lambda z: z.to(d)
+    xs = S(t(x1), None, t(cx), coff=16, act=1)
+    gs = S(t(g1), t(g2), t(cg), coff=32)
+    lib = _lib.load()
+    prev = lib.tamgcn_get_split_mode()
+    seen, orig = [], ops.reduce_sum
+
+    def spy(*a, **k):                                  # the kernel that filled the partial slabs
+        seen.append(lib.tamgcn_last_kernel().decode())
+        return orig(*a, **k)
+    monkeypatch.setattr(ops, 'reduce_sum', spy)
+    try:
+        for mode, bar in ((1, 2e-5), (0, 2e-6)):
+            lib.tamgcn_set_split_mode(mode)
+            del seen[:]
+            dw = ops.wgrad(gs, xs, M=M, K=K, KT=KT, dil=dil, stride=1, pad=pad)
+            torch.cuda.synchronize()
+            name = seen[0] if seen else lib.tamgcn_last_kernel().decode()
+            assert name.startswith('wgrad_glds_kernel') and name.endswith('taps'), name
+            err = float((dw.double().cpu() - ref).abs().max() / ref.abs().max())
+            assert err <= bar, (mode, err)
+    finally:
         lib.tamgcn_set_split_mode(prev)
