@@ -282,7 +282,7 @@ __device__ __forceinline__ void staged_rows(const ConvArgs& a, const float* Tt, 
         for (int c4 = seg; c4 < nc4; c4 += TPR) {
             const int col = c4 << 2;
             const int fr = col / Vs, v = col - fr * Vs;
-            if (vecok && col + 4 <= ncols) {
+            if ((vecok || v + 4 <= Vs) && col + 4 <= ncols) {
                 const long long off = (long long)(t0 + fr) * a.ostride * V + v0 + v;
                 float4 val = *reinterpret_cast<const float4*>(Tt + row * PT + col);
                 val.x = fmaf(pc1, val.x + bia, pc0); val.y = fmaf(pc1, val.y + bia, pc0);
@@ -1054,7 +1054,9 @@ static int plan_conv(const tamgcn_conv_desc* d, ConvPlan* p) {
     const int V = d->V;
     if (V < 1 || V > MAXCOLS) return -1;
     // contiguous 1x1 form: a channel row of the tile is one run of BT*V floats in HBM, whatever V is
-    p->flat = d->KT == 1 && d->stride == 1 && d->up == 1 && d->ostride == 1 && d->pad == 0 && d->T_in == d->T_out && d->T_y == d->T_out;
+    // (the INPUT side: an output written to every ostride-th frame -- the data gradient of a strided 1x1 conv -- only changes
+    // the epilogue's addresses, staged_rows handles it)
+    p->flat = d->KT == 1 && d->stride == 1 && d->up == 1 && d->pad == 0 && d->T_in == d->T_out;
     // joint slices for large skeletons with a temporal halo (V = 64: 8 halo frames are 512 floats per row, the tile 320)
     p->Vs = V; p->nsl = 1;
     if (!p->flat && d->KT > 1 && V > 32 && V % 16 == 0) { p->Vs = 16; p->nsl = V / 16; }
@@ -1344,6 +1346,9 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(const WgradArgs a) {
     // ---- prefetch descriptors (PF only): slot i of this thread -> (row, 4-column group) of each tile
     const int ly4 = (a.BT * V) >> 2, lx4 = (a.TIN * V) >> 2;
     int yr[PF ? WG_NPF : 1], yc[PF ? WG_NPF : 1], xr_[PF ? WG_NPF : 1], xc[PF ? WG_NPF : 1];
+    // frame (inside the chunk) of a slot's first element and how many of its 4 elements lie in that frame: for V % 4 != 0
+    // (rows only dword aligned -- gfx950 takes such 16-byte loads at full rate) a slot may straddle two frames
+    int yf[PF ? WG_NPF : 1], ycn[PF ? WG_NPF : 1], xf[PF ? WG_NPF : 1], xcn[PF ? WG_NPF : 1];
     float4 y1[PF ? WG_NPF : 1], y2[PF ? WG_NPF : 1], x1[PF ? WG_NPF : 1], x2[PF ? WG_NPF : 1];
     if constexpr (PF) {
 #pragma unroll
@@ -1351,9 +1356,24 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(const WgradArgs a) {
             int e = tid + i * NTHREADS;
             int r = e / ly4; yr[i] = r < BMW ? r : -1; yc[i] = (e - r * ly4) << 2;
             r = e / lx4; xr_[i] = r < BKW ? r : -1; xc[i] = (e - r * lx4) << 2;
+            yf[i] = yc[i] / V; ycn[i] = min(4, V - (yc[i] - yf[i] * V));
+            xf[i] = xc[i] / V; xcn[i] = min(4, V - (xc[i] - xf[i] * V));
         }
     }
     const bool gy2 = a.gy.x2 != nullptr, sx2 = a.src.x2 != nullptr;
+    // elements [0, cn) of a slot are valid iff va, elements [cn, 4) iff vb: a whole-slot 16-byte load when both hold,
+    // element loads for a slot that is cut by the start or the end of the row (never touches memory outside the row)
+    auto load_slot = [&](const float* p, int cn, bool va, bool vb) -> float4 {
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (va && vb) o = *reinterpret_cast<const float4*>(p);
+        else if (va || vb) {
+            if (cn > 0 ? va : vb) o.x = p[0];
+            if (cn > 1 ? va : vb) o.y = p[1];
+            if (cn > 2 ? va : vb) o.z = p[2];
+            if (cn > 3 ? va : vb) o.w = p[3];
+        }
+        return o;
+    };
     auto prefetch = [&](int n, int t0) {
         if constexpr (PF) {
             const long long yb = (long long)n * a.gy.ctot * gy_cs + (long long)(a.gy.coff + m0) * gy_cs + (long long)t0 * V;
@@ -1362,16 +1382,19 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
             for (int i = 0; i < WG_NPF; ++i) {
                 y1[i] = make_float4(0.f, 0.f, 0.f, 0.f); y2[i] = y1[i]; x1[i] = y1[i]; x2[i] = y1[i];
-                if (yr[i] >= 0 && yr[i] < mvalid && t0 + yc[i] / V < a.T_out) {
+                if (yr[i] >= 0 && yr[i] < mvalid) {
+                    const int fa = t0 + yf[i], fb = fa + (ycn[i] < 4 ? 1 : 0);
+                    const bool va = fa < a.T_out, vb = fb < a.T_out;
                     long long g = yb + (long long)yr[i] * gy_cs + yc[i];
-                    y1[i] = *reinterpret_cast<const float4*>(a.gy.x1 + g);
-                    if (gy2) y2[i] = *reinterpret_cast<const float4*>(a.gy.x2 + g);
+                    y1[i] = load_slot(a.gy.x1 + g, ycn[i], va, vb);
+                    if (gy2) y2[i] = load_slot(a.gy.x2 + g, ycn[i], va, vb);
                 }
-                int fr = f0 + xc[i] / V;
-                if (xr_[i] >= 0 && xr_[i] < kvalid && fr >= 0 && fr < a.T_in) {
+                if (xr_[i] >= 0 && xr_[i] < kvalid) {
+                    const int fa = f0 + xf[i], fb = fa + (xcn[i] < 4 ? 1 : 0);
+                    const bool va = fa >= 0 && fa < a.T_in, vb = fb >= 0 && fb < a.T_in;
                     long long g = xb + (long long)xr_[i] * x_cs + xc[i];
-                    x1[i] = *reinterpret_cast<const float4*>(a.src.x1 + g);
-                    if (sx2) x2[i] = *reinterpret_cast<const float4*>(a.src.x2 + g);
+                    x1[i] = load_slot(a.src.x1 + g, xcn[i], va, vb);
+                    if (sx2) x2[i] = load_slot(a.src.x2 + g, xcn[i], va, vb);
                 }
             }
         }
@@ -1384,22 +1407,39 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(const WgradArgs a) {
                 if (yr[i] >= 0) {
                     const int r = yr[i];
                     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (r < mvalid && t0 + yc[i] / V < a.T_out) {
+                    const int fa = t0 + yf[i], fb = fa + (ycn[i] < 4 ? 1 : 0);
+                    const bool va = fa < a.T_out, vb = fb < a.T_out;
+                    if (r < mvalid && (va || vb)) {
                         float c1 = cfY[r], c2 = cfY[BMW + r], c0 = cfY[2 * BMW + r];
                         o.x = wg_apply(y1[i].x, y2[i].x, c1, c2, c0, a.gy.act); o.y = wg_apply(y1[i].y, y2[i].y, c1, c2, c0, a.gy.act);
                         o.z = wg_apply(y1[i].z, y2[i].z, c1, c2, c0, a.gy.act); o.w = wg_apply(y1[i].w, y2[i].w, c1, c2, c0, a.gy.act);
+                        if (!(va && vb)) {                        // a slot cut by the end of the row: padding is zero AFTER the prologue
+                            const int cn = ycn[i];
+                            if (!(cn > 0 ? va : vb)) o.x = 0.f;
+                            if (!(cn > 1 ? va : vb)) o.y = 0.f;
+                            if (!(cn > 2 ? va : vb)) o.z = 0.f;
+                            if (!(cn > 3 ? va : vb)) o.w = 0.f;
+                        }
                     }
                     float2* d = reinterpret_cast<float2*>(Ys + r * a.PY + yc[i]);
                     d[0] = make_float2(o.x, o.y); d[1] = make_float2(o.z, o.w);
                 }
                 if (xr_[i] >= 0) {
                     const int r = xr_[i];
-                    const int fr = f0 + xc[i] / V;
+                    const int fa = f0 + xf[i], fb = fa + (xcn[i] < 4 ? 1 : 0);
+                    const bool va = fa >= 0 && fa < a.T_in, vb = fb >= 0 && fb < a.T_in;
                     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (r < kvalid && fr >= 0 && fr < a.T_in) {
+                    if (r < kvalid && (va || vb)) {
                         float c1 = cfX[r], c2 = cfX[BKW + r], c0 = cfX[2 * BKW + r];
                         o.x = wg_apply(x1[i].x, x2[i].x, c1, c2, c0, a.src.act); o.y = wg_apply(x1[i].y, x2[i].y, c1, c2, c0, a.src.act);
                         o.z = wg_apply(x1[i].z, x2[i].z, c1, c2, c0, a.src.act); o.w = wg_apply(x1[i].w, x2[i].w, c1, c2, c0, a.src.act);
+                        if (!(va && vb)) {
+                            const int cn = xcn[i];
+                            if (!(cn > 0 ? va : vb)) o.x = 0.f;
+                            if (!(cn > 1 ? va : vb)) o.y = 0.f;
+                            if (!(cn > 2 ? va : vb)) o.z = 0.f;
+                            if (!(cn > 3 ? va : vb)) o.w = 0.f;
+                        }
                     }
                     float2* d = reinterpret_cast<float2*>(Xs + r * a.PX + xc[i]);
                     d[0] = make_float2(o.x, o.y); d[1] = make_float2(o.z, o.w);
@@ -1432,7 +1472,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll 5
                 for (int v4 = 0; v4 < V4; ++v4) {
                     int v = v4 * 4 + kq;
-                    bool vok = VEC || v < V;
+                    bool vok = v < V;
                     int vc = vok ? v : 0;
                     float av[WMT];
 #pragma unroll
@@ -1742,9 +1782,12 @@ template <int KT, int WMT, int WKT, bool PS = false>
 static int launch_wgrad(WgradArgs& a, hipStream_t s) {
     constexpr int BMW = PS ? 16 : 2 * WMT * 16, BKW = PS ? 16 : 2 * WKT * 16;
     const int V = a.V;
-    const bool vec = (V % 4) == 0;
+    // 16-byte slots: always for V % 4 == 0; the p-split kernel also takes rows that are only dword aligned (V = 25), its
+    // slots then may straddle two frames -- the chunk must still be whole slots on both sides
+    const bool ragged = (V % 4) != 0;
+    const bool vec = !ragged || PS;
     int BT = 8;
-    if (BT > a.T_out) BT = a.T_out;
+    if (BT > a.T_out && !ragged) BT = a.T_out;
     size_t lds;
     for (;;) {
         a.BT = BT;
@@ -1754,6 +1797,7 @@ static int launch_wgrad(WgradArgs& a, hipStream_t s) {
         lds = sizeof(float) * ((size_t)BMW * a.PY + (size_t)BKW * a.PX + 3 * (BMW + BKW));
         bool slots_ok = !(vec && (KT == 1 || PS)) ||
                         (BMW * (BT * V / 4) <= WG_NPF * NTHREADS && BKW * (a.TIN * V / 4) <= WG_NPF * NTHREADS);
+        if (ragged && PS && ((BT * V) % 4 != 0 || (a.TIN * V) % 4 != 0)) slots_ok = false;
         if (PS && lds < sizeof(float) * 4 * KT * 256) lds = sizeof(float) * 4 * KT * 256;   // the final cross-wave reduction
         if ((lds <= 48 * 1024 && slots_ok) || BT == 1) {
             if (!slots_ok) { tamgcn_set_error("tamgcn_wgrad: prefetch slots exceeded (V=%d stride=%d)", V, a.stride); return -1; }
@@ -1881,7 +1925,7 @@ extern "C" int tamgcn_wgrad(const tamgcn_wgrad_desc* d, void* stream) {
             if (rc == -1) rc = launch_wgrad<3, 1, 1>(a, s);
             break;
         case 5:
-            rc = (d->M <= 16 && d->K <= 16 && d->V % 4 == 0) ? launch_wgrad<5, 1, 1, true>(a, s) : -1;
+            rc = (d->M <= 16 && d->K <= 16 && (d->V % 4 == 0 || d->stride == 1)) ? launch_wgrad<5, 1, 1, true>(a, s) : -1;
             if (rc == -1 && wmt != 1) rc = launch_wgrad<5, 2, 2>(a, s);
             if (rc == -1) rc = launch_wgrad<5, 1, 1>(a, s);
             break;

@@ -50,6 +50,14 @@ CONV_CASES = [
     (2, 24, 24, 10, 20, 9, 1, 1),
     (2, 64, 64, 5, 25, 5, 2, 1),       # T - pad = 1 frame: too short for a window, stays on the register-staged kernel
     (2, 48, 80, 7, 25, 1, 1, 1),       # 1x1, rows of 175 = 5 * 32 + 15 floats
+    # 16-channel k x 1 at V = 25: the p-split weight-gradient kernel with 16-byte slots on dword-aligned rows (slots
+    # straddling two frames, rows cut at both ends), chunk lengths 8 and 4 frames, T not a multiple of either
+    (2, 64, 128, 13, 25, 1, 1, 2),     # strided 1x1 at V = 25: its data gradient writes every second frame from the LDS-DMA GEMM
+    (3, 32, 128, 16, 20, 1, 1, 2),
+    (2, 16, 16, 13, 25, 5, 1, 1),
+    (2, 16, 16, 11, 25, 5, 2, 1),
+    (3, 16, 12, 7, 25, 5, 1, 1),
+    (1, 16, 16, 3, 25, 5, 2, 1),
 ]
 
 

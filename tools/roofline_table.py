@@ -13,7 +13,8 @@ from tam_gcn_amd.models.ctrgcn import Model
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--side', type=int, default=0)
-ap.add_argument('--batch', type=int, default=256)
+ap.add_argument('--batch', type=int, default=0)
+ap.add_argument('--config', default='ucla', choices=['ucla', 'ntu'])
 a = ap.parse_args()
 Fn.USE_SIDE_STREAMS = bool(a.side)
 HBM, MF = 6.0e12, bench.F32_MFMA_PEAK        # 6 TB/s: what a streaming kernel reaches on this box
@@ -26,11 +27,14 @@ def sig(name, args):
         return name
     if name == 'tamgcn_conv':
         ex = (1 if d.add1 else 0) + (1 if d.add2 else 0) + (1 if d.mask else 0) + (1 if d.aux else 0)
-        return f'conv K{d.K} M{d.M} KT{d.KT} T{d.T_in}>{d.T_out} src{bench._src_reads(d.src)} ex{ex} wm{d.wmode} st{1 if d.stats_part else 0} s{d.stride} N{d.N}'
+        return f'conv K{d.K} M{d.M} KT{d.KT} T{d.T_in}>{d.T_out} src{bench._src_reads(d.src)} ex{ex} wm{d.wmode} st{1 if d.stats_part else 0} s{d.stride} N{d.N}' + (f' [al{(d.src.x1 or 0) % 16}/{(d.src.x2 or 0) % 16}/{(d.w or 0) % 16} coff{d.src.coff}/{d.src.ctot} ycoff{d.ycoff}/{d.yctot} os{d.ostride} up{d.up} bc{1 if d.bcast else 0}]' if os.environ.get('RT_DETAIL') else '')
     if name == 'tamgcn_wgrad':
         return f'wgrad K{d.K} M{d.M} KT{d.KT} T{d.T_in}>{d.T_out} gy{bench._src_reads(d.gy)} src{bench._src_reads(d.src)} N{d.N}'
     if name.startswith('tamgcn_ctrgc'):
         return f'{name[7:]} {d.Cin}>{d.Cout} T{d.T}'
+    if name in ('tamgcn_add_act_fwd', 'tamgcn_add_act_bwd', 'tamgcn_gcn_tail_fwd', 'tamgcn_gcn_tail_bwd', 'tamgcn_gcn_mid_bwd'):
+        ints = [x for x in args if isinstance(x, int)]
+        return f'{name[7:]} ' + 'x'.join(str(v) for v in ints[-4:])
     return name
 
 
@@ -55,11 +59,16 @@ dev = torch.device('cuda:0')
 probe = P(_lib.load())
 _lib._lib = probe
 torch.manual_seed(0)
-m = Model(**bench.MODEL_ARGS)
+if a.config == 'ntu':
+    margs = dict(num_class=60, num_point=25, num_person=2, graph='graph.ntu_rgb_d.Graph', graph_args=dict(labeling_mode='spatial'))
+    shape = (a.batch or 128, 3, 300, 25, 2)
+else:
+    margs, shape = bench.MODEL_ARGS, (a.batch or 256, 3, bench.T_FRAMES, bench.V_JOINTS, 1)
+m = Model(**margs)
 bench.dedegenerate_(m)
 m = m.to(dev).train()
-x = (torch.rand(a.batch, 3, bench.T_FRAMES, bench.V_JOINTS, 1) * 2 - 1).to(dev)
-lab = torch.randint(0, 10, (a.batch,)).to(dev)
+x = (torch.rand(*shape) * 2 - 1).to(dev)
+lab = torch.randint(0, margs['num_class'], (shape[0],)).to(dev)
 ce = Fn.CrossEntropyLoss()
 
 
