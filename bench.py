@@ -73,7 +73,7 @@ class _Probe:
         if not name.startswith('tamgcn_') or name in ('tamgcn_last_error', 'tamgcn_last_kernel', 'tamgcn_version', 'tamgcn_conv_nparts',
                                                      'tamgcn_ew_nparts', 'tamgcn_ctrgc_lds_bytes', 'tamgcn_get_split_mode',
                                                      'tamgcn_set_split_mode', 'tamgcn_wgrad_max_split', 'tamgcn_ctrgc_tiled_supported',
-                                                     'tamgcn_ctrgc_tiled_chunks', 'tamgcn_set_split3_fwd'):
+                                                     'tamgcn_ctrgc_tiled_chunks', 'tamgcn_set_split3_fwd', 'tamgcn_set_rows128'):
             return fn
 
         def wrapped(*args):

@@ -69,6 +69,11 @@ int         tamgcn_set_split_mode(int mode);
  * channels run as a three-term bf16 split (six v_mfma_f32_16x16x32_bf16 per K = 32 step: hh, hm, mh, hl, lh, mm), which
  * reproduces the fp32 product to ~1.2e-7 relative (outputs within 1e-6 of the exact kernels, tools/split3_check.py). */
 int         tamgcn_set_split3_fwd(int on);
+/* Opt-in (initial value from TAMGCN_ROWS128, default 0): forward 1x1 convolutions into >= 128 channels whose operand
+ * prologue is linear run on a 128-row tile of the LDS-DMA GEMM with the exact fp32-input MFMA (half the activation traffic
+ * per flop of the 64-row kernel, but one workgroup per CU on a two-stage ring: measured slower, NTU step 186 vs 177 ms).
+ * Tests compare the two. */
+int         tamgcn_set_rows128(int on);
 /* bytes of LDS the CTRGC kernels need for (S subsets, V joints, R rel-channels): the fused LDS-resident family for
  * V in {20, 25}, the tiled large-skeleton family (tamgcn_ctrgc_tiled_*) for V in {32, 64};
  * <0 if the shape is unsupported.  Lets the host fail early and loudly. */

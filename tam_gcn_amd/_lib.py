@@ -77,6 +77,7 @@ SIGNATURES = {
     'tamgcn_get_split_mode': (_i, []),
     'tamgcn_set_split_mode': (_i, [_i]),
     'tamgcn_set_split3_fwd': (_i, [_i]),
+    'tamgcn_set_rows128': (_i, [_i]),
     'tamgcn_conv_nparts': (_i, [C.POINTER(ConvDesc)]),
     'tamgcn_conv': (_i, [C.POINTER(ConvDesc), _p]),
     'tamgcn_wgrad_max_split': (_i, [C.POINTER(WgradDesc)]),

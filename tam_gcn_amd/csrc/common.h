@@ -15,6 +15,7 @@ void tamgcn_set_error(const char* fmt, ...);
 void tamgcn_note_kernel(const char* fmt, ...);   // symbol of the kernel the last ABI call launched (per thread)
 int tamgcn_split3_fwd(void);                     // three-term (fp32-exact) split in the forward 1x1 GEMMs into >= 128 channels
 int tamgcn_split64(void);
+int tamgcn_rows128(void);        // forward 1x1 convs into >= 128 channels on the 128-row exact-fp32 tile (TAMGCN_ROWS128, default 0: measured slower)
 int tamgcn_wgrad_taps(void);     // k x 1 weight gradients on the LDS-DMA kernel (TAMGCN_WGRAD_TAPS, default 1)                        // two-term split data gradients on 64-row tiles (C = 64 layers)
 int tamgcn_split_mode(void);                     // TAMGCN_SPLIT_BF16: 0 = exact fp32-input MFMA everywhere; 1 (default) = split-fp32 on the bf16 matrix cores in the
                                                  // weight-gradient GEMMs (their results never feed an activation); 2 = also the forward x3 GEMM

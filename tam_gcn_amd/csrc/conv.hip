@@ -959,6 +959,7 @@ __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs
             for (int e = 0; e < 8; ++e) { cs[e] = cc1[4 * e]; c0[e] = c < nchk ? cf[2 * K + k0 + 4 * e + kq] : 0.f; }
         }
         bf16x8_t ah[GS_MT], am[GS_MT], al[GS_MT];
+        float af[TERMS == 1 ? GS_MT : 1][8];                       // TERMS == 1: the A values themselves (exact fp32-input MFMA)
 #pragma unroll
         for (int mt = 0; mt < GS_MT; ++mt) {
             f32x4 v0, v1;
@@ -977,7 +978,10 @@ __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs
                     v0[e] *= cs[e]; v1[e] *= cs[e + 4];
                 }
             }
-            if constexpr (TERMS == 3) split3_bf16x8(v0, v1, ah[mt], am[mt], al[mt]);
+            if constexpr (TERMS == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { af[mt][e] = v0[e]; af[mt][e + 4] = v1[e]; }
+            } else if constexpr (TERMS == 3) split3_bf16x8(v0, v1, ah[mt], am[mt], al[mt]);
             else split_bf16x8(v0, v1, ah[mt], al[mt]);
         }
 #pragma unroll
@@ -985,7 +989,14 @@ __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs
             f32x4 v0, v1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v0[e] = st[(4 * e + kq) * LB + bslot[cc]]; v1[e] = st[(4 * (e + 4) + kq) * LB + bslot[cc]]; }
-            if constexpr (TERMS == 3) {
+            if constexpr (TERMS == 1) {                           // lane (j, kq) holds k = 4e + kq: step e of eight K = 4 MFMAs
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float bv = e < 4 ? v0[e & 3] : v1[e & 3];
+#pragma unroll
+                    for (int mt = 0; mt < GS_MT; ++mt) acc[mt][cc] = mfma16(af[mt][e], bv, acc[mt][cc]);
+                }
+            } else if constexpr (TERMS == 3) {
                 bf16x8_t bh, bm, bl;
                 split3_bf16x8(v0, v1, bh, bm, bl);
 #pragma unroll
@@ -1163,10 +1174,20 @@ extern "C" int tamgcn_conv(const tamgcn_conv_desc* d, void* stream) {
                         lds_split <= 160 * 1024 && !d->post_coef;
     const bool big = big_ok && d->wmode == 1 && !d->stats_part && (d->M >= 128 || tamgcn_split64());
     const bool big3 = big_ok && d->wmode == 0 && d->M >= 128 && tamgcn_split3_fwd();
-    if (big || big3) {
+    // exact fp32-input MFMA on the same 128-row tile (forward 1x1 convs into >= 128 channels with a linear operand): half the
+    // activation traffic per flop of the 64-row kernel -- opt-in: one workgroup per CU on the two-stage ring exposes every
+    // stall, measured 0.32 of the fp32 MFMA peak against the 64-row kernel's 0.35-0.45 (NTU step 186 vs 177 ms)
+    const bool big1 = glds && !big3 && d->wmode == 0 && d->M >= 128 && d->src.act == 0 && d->M % 4 == 0 && d->K % GS_BK == 0 &&
+                      lds_split <= 160 * 1024 && !d->post_coef && tamgcn_rows128();
+    if (big || big3 || big1) {
         const int nmt = ceil_div(d->M, bmt);
         const unsigned nblk = (unsigned)(d->N * p.ntt * nmt);
-        if (big3) {
+        if (big1) {
+            static tg_devmask f7 = 0;
+            tg_allow_lds((const void*)conv1x1_glds_split_kernel<1, true, 4>, 160 * 1024, &f7);
+            hipLaunchKernelGGL((conv1x1_glds_split_kernel<1, true, 4>), dim3(nblk), dim3(G_NT), lds_split, (hipStream_t)stream, a, p.ntt, nmt);
+            tamgcn_note_kernel("conv1x1_glds_rows128_kernel<f32, fwd>");
+        } else if (big3) {
             static tg_devmask f3 = 0;
             tg_allow_lds((const void*)conv1x1_glds_split_kernel<3, true, 4>, 160 * 1024, &f3);
             hipLaunchKernelGGL((conv1x1_glds_split_kernel<3, true, 4>), dim3(nblk), dim3(G_NT), lds_split, (hipStream_t)stream, a, p.ntt, nmt);

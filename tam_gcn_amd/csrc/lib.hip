@@ -45,6 +45,13 @@ int tamgcn_split_mode(void) {
 // by the matrix pipe -- while its 2-8x fp32 rounding noise moves more ReLU masks in the 4-clip SGD fixtures: not the default.
 // two-term split data-gradient GEMMs also for the 64-channel layers (64-row tiles): opt-in (TAMGCN_SPLIT64=1).  Measured r02: the
 // 2.18 ms of exact kernels it replaces become 2.31 ms -- those launches are bound by their prologue / epilogue latency, not by the matrix pipe.
+static int g_rows128 = -1;
+int tamgcn_rows128(void) {
+    if (g_rows128 < 0) { const char* e = getenv("TAMGCN_ROWS128"); g_rows128 = e ? (atoi(e) != 0) : 0; }
+    return g_rows128;
+}
+extern "C" int tamgcn_set_rows128(int on) { g_rows128 = on ? 1 : 0; return 0; }
+
 int tamgcn_wgrad_taps(void) {
     static int v = -1;
     if (v < 0) { const char* e = getenv("TAMGCN_WGRAD_TAPS"); v = e ? atoi(e) : 1; }

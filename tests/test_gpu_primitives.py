@@ -418,16 +418,29 @@ def test_three_term_split_forward_gemm_matches_exact_kernels():
             coef = torch.stack((r(K) + 1.5, r(K), r(K)))
             w, b = r(M, K) * K ** -0.5, r(M)
             src = S(x1, x2, coef) if two else S(x1)
-            lib.tamgcn_set_split_mode(0)
+            lib.tamgcn_set_split_mode(0); lib.tamgcn_set_rows128(0)
             y0, p0 = ops.conv(src, K=K, w=w, bias=b, M=M, stats=True)
+            assert b'conv1x1_glds_kernel' in lib.tamgcn_last_kernel()
             lib.tamgcn_set_split_mode(1); lib.tamgcn_set_split3_fwd(1)
             y1, p1 = ops.conv(src, K=K, w=w, bias=b, M=M, stats=True)
             assert b'split_kernel<3' in lib.tamgcn_last_kernel()
             lib.tamgcn_set_split3_fwd(0)
             assert float((y0 - y1).abs().max()) <= 2e-6 * float(y0.abs().max())
             assert float((p0.sum(2) - p1.sum(2)).abs().max()) <= 2e-6 * float(p0.sum(2).abs().max())
+            # opt-in: the same exact fp32-input MFMA on the 128-row tile (K % 32 == 0)
+            lib.tamgcn_set_rows128(1)
+            y2, p2 = ops.conv(src, K=K, w=w, bias=b, M=M, stats=True)
+            assert b'rows128' in lib.tamgcn_last_kernel()
+            a = (coef[0][None, :, None, None] * x1 + coef[1][None, :, None, None] * x2 + coef[2][None, :, None, None]) if two else x1
+            ref = torch.einsum('mk,nktv->nmtv', w.double(), a.double()) + b.double()[None, :, None, None]
+            e64, e128 = float((y0.double() - ref).abs().max()), float((y2.double() - ref).abs().max())
+            # (the linear prologue is folded into the weight fragment there: one more rounding per product)
+            assert e128 <= max(2.0 * e64, 2e-6 * float(ref.abs().max())), (e64, e128)
+            assert float((y0 - y2).abs().max()) <= 2e-6 * float(y0.abs().max())
+            assert float((p0.sum(2) - p2.sum(2)).abs().max()) <= 2e-6 * float(p0.sum(2).abs().max())
     finally:
         lib.tamgcn_set_split3_fwd(0)
+        lib.tamgcn_set_rows128(0)
         lib.tamgcn_set_split_mode(prev)
 
 

@@ -11,9 +11,10 @@ ap.add_argument('--K', type=int, default=64); ap.add_argument('--M', type=int, d
 ap.add_argument('--T', type=int, default=64); ap.add_argument('--N', type=int, default=256)
 ap.add_argument('--two', action='store_true'); ap.add_argument('--nostats', action='store_true')
 ap.add_argument('--bwd', action='store_true'); ap.add_argument('--iters', type=int, default=4)
+ap.add_argument('--V', type=int, default=20); ap.add_argument('--plain', action='store_true')
 a = ap.parse_args()
 dev = torch.device('cuda:0')
-N, V, K, M, T = a.N, 20, a.K, a.M, a.T
+N, V, K, M, T = a.N, a.V, a.K, a.M, a.T
 x = torch.randn(N, K, T, V, device=dev); x2 = torch.randn(N, K, T, V, device=dev) if a.two else None
 coef = torch.randn(3, K, device=dev)
 if a.bwd:
@@ -21,7 +22,7 @@ if a.bwd:
     f = lambda: ops.conv(S(x, x2, coef if a.two else None), K=K, w=w, bias=None, M=M, wmode=1, bcast=bc, bcast_scale=0.1, add1=a1)
 else:
     w = torch.randn(M, K, 1, 1, device=dev) * 0.1; b = torch.randn(M, device=dev)
-    f = lambda: ops.conv(S(x, x2, coef), K=K, w=w, bias=b, M=M, stats=not a.nostats)
+    f = lambda: ops.conv(S(x, x2, None if a.plain else coef), K=K, w=w, bias=b, M=M, stats=not a.nostats)
 for _ in range(a.iters):
     f()
 torch.cuda.synchronize()
