@@ -37,6 +37,7 @@ import torch.distributed as dist                        # noqa: E402
 
 HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md chip table
 F32_MFMA_PEAK = 157.3e12   # FLOP/s, v_mfma_f32_16x16x4_f32 (= fp32 vector peak)
+BF16_MFMA_PEAK = 2.5e15     # FLOP/s, dense bf16 MFMA (MI355X_MICROARCH.md; the headline figures with 2:1 sparsity are not used)
 
 MODEL_ARGS = dict(num_class=10, num_point=20, num_person=1, graph='graph.ucla.Graph',
                   graph_args=dict(labeling_mode='spatial'))
@@ -178,7 +179,15 @@ def roofline_of(agg):
     timed = {k: v for k, v in agg.items() if v['bytes'] > 0}
     if not timed:
         return None, {}
-    name = max(timed, key=lambda k: timed[k]['ms'])
+    order = sorted(timed, key=lambda k: -timed[k]['ms'])
+    name = order[0]
+    # The fused CTRGC forward and the split-bf16 data-gradient GEMM hold near-equal shares (6.9 ms each per two steps):
+    # within 10 % of the top the object stays on the fused CTRGC forward -- the kernel earlier rounds reported and the
+    # one north_star names -- instead of flipping with run-to-run noise; roofline_top3 lists the leaders either way.
+    for k in order:
+        if k.startswith('ctrgc_fwd') and timed[k]['ms'] >= 0.9 * timed[name]['ms']:
+            name = k
+            break
     a = timed[name]
     sec = a['ms'] * 1e-3
     bw, fl = a['bytes'] / sec, a['flops'] / sec
@@ -202,6 +211,16 @@ def roofline_of(agg):
     else:
         r = dict(bound='hbm', achieved=bw / 1e9, peak=HBM_PEAK / 1e9, unit='GB/s', frac=bw / HBM_PEAK)
     r.update(common)
+    top = []
+    for k in order[:3]:
+        v = timed[k]
+        sk = v['ms'] * 1e-3
+        # the split GEMMs spend three bf16 MFMAs per fp32 product: their matrix roof is the dense bf16 peak / 3
+        peak = BF16_MFMA_PEAK / 3.0 if ('split_kernel<2' in k or ', split,' in k) else F32_MFMA_PEAK
+        fh, fm = v['bytes'] / sk / HBM_PEAK, v['flops'] / sk / peak
+        top.append(dict(kernel=k, ms=round(v['ms'], 3), launches=v['calls'], bound='mfma' if v['flops'] / peak > v['bytes'] / HBM_PEAK else 'hbm',
+                        hbm_frac=round(fh, 4), mfma_frac=round(fm, 4), mfma_peak_tflops=round(peak / 1e12, 1)))
+    r['top3'] = top
     shares = {k: round(v['ms'], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])}
     return r, shares
 

@@ -1186,22 +1186,22 @@ extern "C" int tamgcn_conv(const tamgcn_conv_desc* d, void* stream) {
             static tg_devmask f7 = 0;
             tg_allow_lds((const void*)conv1x1_glds_split_kernel<1, true, 4>, 160 * 1024, &f7);
             hipLaunchKernelGGL((conv1x1_glds_split_kernel<1, true, 4>), dim3(nblk), dim3(G_NT), lds_split, (hipStream_t)stream, a, p.ntt, nmt);
-            tamgcn_note_kernel("conv1x1_glds_rows128_kernel<f32, fwd>");
+            tamgcn_note_kernel("conv1x1_glds_split_kernel<1, true, 4>");   // TERMS = 1: no split, exact fp32 (rows128)
         } else if (big3) {
             static tg_devmask f3 = 0;
             tg_allow_lds((const void*)conv1x1_glds_split_kernel<3, true, 4>, 160 * 1024, &f3);
             hipLaunchKernelGGL((conv1x1_glds_split_kernel<3, true, 4>), dim3(nblk), dim3(G_NT), lds_split, (hipStream_t)stream, a, p.ntt, nmt);
-            tamgcn_note_kernel("conv1x1_glds_split_kernel<3, fwd>");
+            tamgcn_note_kernel("conv1x1_glds_split_kernel<3, true, 4>");
         } else if (bmt == 128) {
             static tg_devmask fs = 0;
             tg_allow_lds((const void*)conv1x1_glds_split_kernel<2, false, 4>, 160 * 1024, &fs);
             hipLaunchKernelGGL((conv1x1_glds_split_kernel<2, false, 4>), dim3(nblk), dim3(G_NT), lds_split, (hipStream_t)stream, a, p.ntt, nmt);
-            tamgcn_note_kernel("conv1x1_glds_split_kernel");
+            tamgcn_note_kernel("conv1x1_glds_split_kernel<2, false, 4>");
         } else {
             static tg_devmask f6 = 0;
             tg_allow_lds((const void*)conv1x1_glds_split_kernel<2, false, 2>, 160 * 1024, &f6);
             hipLaunchKernelGGL((conv1x1_glds_split_kernel<2, false, 2>), dim3(nblk), dim3(G_NT), lds_split, (hipStream_t)stream, a, p.ntt, nmt);
-            tamgcn_note_kernel("conv1x1_glds_split_kernel<2, bwd, 64 rows>");
+            tamgcn_note_kernel("conv1x1_glds_split_kernel<2, false, 2>");
         }
     } else if (glds) {
         const int nmt = ceil_div(d->M, G_BMT);

@@ -430,7 +430,7 @@ def test_three_term_split_forward_gemm_matches_exact_kernels():
             # opt-in: the same exact fp32-input MFMA on the 128-row tile (K % 32 == 0)
             lib.tamgcn_set_rows128(1)
             y2, p2 = ops.conv(src, K=K, w=w, bias=b, M=M, stats=True)
-            assert b'rows128' in lib.tamgcn_last_kernel()
+            assert b'split_kernel<1, true, 4>' in lib.tamgcn_last_kernel()
             a = (coef[0][None, :, None, None] * x1 + coef[1][None, :, None, None] * x2 + coef[2][None, :, None, None]) if two else x1
             ref = torch.einsum('mk,nktv->nmtv', w.double(), a.double()) + b.double()[None, :, None, None]
             e64, e128 = float((y0.double() - ref).abs().max()), float((y2.double() - ref).abs().max())
