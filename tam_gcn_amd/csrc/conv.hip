@@ -608,6 +608,9 @@ __global__ __launch_bounds__(G_NT, 2) void conv1x1_glds_kernel(const ConvArgs a,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kq = lane >> 4, wm = wave >> 2, wn = wave & 3;
     const int V = a.V, K = a.K, LB = a.LB;
+    // odd k rows are rotated so that the two rows a 32-lane half reads sit 16 banks apart: a source column c of an odd row
+    // sits at position c - rot, LB - rot == 16 (mod 32) (16 columns at LB % 32 == 0; V = 25 tiles have LB = 300: 28 columns).  LB % 4 == 0 keeps rot a whole 16-byte slot.
+    const int rot = ((LB & 31) + 16) & 31;
     // workgroup -> (sample, frame tile, channel tile); the channel tiles of one (n, tt) share an XCD's L2
     int g, mtile;
     {
@@ -643,7 +646,7 @@ __global__ __launch_bounds__(G_NT, 2) void conv1x1_glds_kernel(const ConvArgs a,
         const int grp = rem / NQ, q = rem - grp * NQ;
         const int f = q * 256 + lane * 4;                         // float index inside the 4-row group
         const int r = f / LB, off = f - r * LB;
-        int col = off + ((r & 1) << 4);                           // source column of this LDS slot
+        int col = off + (r & 1) * rot;                            // source column of this LDS slot
         if (col >= LB) col -= LB;
         b_ok[i] = idok && r < 4 && col < ncols;
         b_rel[i] = (int)((grp * 4 + r) * TV) + col + src * 0x40000000;   // bit 30 tags the second source
@@ -706,7 +709,7 @@ __global__ __launch_bounds__(G_NT, 2) void conv1x1_glds_kernel(const ConvArgs a,
     for (int c = 0; c < G_CWT; ++c) {
         int col = (wn * G_CWT + c) * 16 + j;
         if (col >= ncols) col = 0;                                // padding tile: in-bounds data, never stored
-        int sl = col - ((kq & 1) << 4);
+        int sl = col - (kq & 1) * rot;
         bslot[c] = sl < 0 ? sl + LB : sl;
     }
     int aoff[BK / 4][G_MT];                                       // A fragment offsets inside a stage's A image
@@ -834,6 +837,9 @@ __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kq = lane >> 4, wm = wave >> 2, wn = wave & 3;
     const int V = a.V, K = a.K, LB = a.LB;
+    // odd k rows are rotated so that the two rows a 32-lane half reads sit 16 banks apart: a source column c of an odd row
+    // sits at position c - rot, LB - rot == 16 (mod 32) (16 columns at LB % 32 == 0; V = 25 tiles have LB = 300: 28 columns).  LB % 4 == 0 keeps rot a whole 16-byte slot.
+    const int rot = ((LB & 31) + 16) & 31;
     int g, mtile;
     {
         const int L = blockIdx.x, ng = a.N * ntt;
@@ -870,7 +876,7 @@ __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs
         const int grp = (idok ? id : 0) / NQ, q = (idok ? id : 0) - grp * NQ;
         const int f = q * 256 + lane * 4;
         const int r = f / LB, off = f - r * LB;
-        int col = off + ((r & 1) << 4);
+        int col = off + (r & 1) * rot;
         if (col >= LB) col -= LB;
         b_ok[i] = idok && r < 4 && col < ncols;
         b_rel[i] = (int)((grp * 4 + r) * TV) + col;
@@ -924,7 +930,7 @@ __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs
     for (int c = 0; c < G_CWT; ++c) {
         int col = (wn * G_CWT + c) * 16 + j;
         if (col >= ncols) col = 0;
-        int sl = col - ((kq & 1) << 4);
+        int sl = col - (kq & 1) * rot;
         bslot[c] = sl < 0 ? sl + LB : sl;
     }
     int aoff[GS_MT];                                               // channel of row tile mt, swizzled for this lane's k parity
