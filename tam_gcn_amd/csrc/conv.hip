@@ -1881,10 +1881,11 @@ static bool wgrad_glds_plan(const tamgcn_wgrad_desc* d, int* wmt, int* wkt) {
                         (uintptr_t)(d->src.x2 ? d->src.x2 : d->src.x1)) & 15) == 0;
     // 1x1, or k x 1 with "same" padding (one window per tap); every window holds at least two 32-element chunks.
     // The 16-channel temporal branches stay on the register-staged kernels (one 16x16 tile: nothing for 8 waves to share;
-    // measured r02: N-UCLA step 31.1 vs 30.2 ms, NTU 1.33 vs 1.0 ms per launch); TAMGCN_WGRAD_TAPS=2 sends them here too,
+    // measured r02: N-UCLA step 31.1 vs 30.2 ms, NTU 1.33 vs 1.0 ms per launch), and so do the 32-channel ones where that
+    // kernel has its 16-byte form (V % 4 == 0: 51 vs 114 us per launch at N-UCLA; at V = 25 the tap form wins 672 vs 896 us); TAMGCN_WGRAD_TAPS=2 sends them here too,
     // =0 disables the tap form.
     const bool taps = d->KT > 1 && d->pad == d->dil * (d->KT - 1) / 2 && (d->dil * (d->KT - 1)) % 2 == 0 && tamgcn_wgrad_taps() &&
-                      (d->M > 16 || d->K > 16 || tamgcn_wgrad_taps() == 2);
+                      (d->M > 32 || d->K > 32 || (d->V % 4 != 0 && (d->M > 16 || d->K > 16)) || tamgcn_wgrad_taps() == 2);
     bool glds = (taps || (d->KT == 1 && d->pad == 0)) && d->stride == 1 && d->T_in == d->T_out && al16 &&
                 (long long)(d->T_out - d->pad) * d->V >= 2 * W_PC;
     if (!glds) return false;

@@ -165,7 +165,7 @@ def wgrad(gy, src, M, K, KT=1, dil=1, stride=1, pad=0, rows=None):
     per_clip = max(gy.x1.shape[1] * T_out * V, src.x1.shape[1] * T_in * V)
     chunks = n_chunks(N, per_clip) if N * per_clip > CHUNK_ELEMS else [(0, N)]
     # same tile rule as wgrad_tile() in csrc/conv.hip: aim at ~4 resident workgroups per CU
-    taps = KT > 1 and stride == 1 and T_in == T_out and (M > 16 or K > 16)      # one window per tap on the LDS-DMA kernel
+    taps = KT > 1 and stride == 1 and T_in == T_out and (M > 32 or K > 32 or (V % 4 != 0 and (M > 16 or K > 16)))      # one window per tap on the LDS-DMA kernel
     if KT == 1 or taps:
         bm, bk = (64 if M <= 64 else 128), (64 if K <= 64 else 128)
     elif KT == 9:
