@@ -404,3 +404,37 @@ def test_eval_fused_path_and_coefficient_cache(monkeypatch):
         counts.append(cnt.n)
     monkeypatch.setattr(_lib, '_lib', real)
     assert counts[0] <= 125 and counts[0] <= counts[1] - 40, counts
+
+
+def test_graphed_forward_replays_the_eval_path(golden_models):
+    """tam_gcn_amd.inference.GraphedForward: the HIP-graph replay of the eval forward returns the eager logits bit for bit,
+    for several inputs and two batch shapes, follows a parameter change after reset(), and extract_feature works too."""
+    from tam_gcn_amd.inference import GraphedForward
+    tag, margs, shape = next(c for c in MODEL_CASES if c[0] == 'ucla_t64')
+    dev = torch.device('cuda:0')
+    m = M.Model(**margs)
+    fill_state_(m.state_dict(), seed=MODEL_PARAM_SEED)
+    m = m.to(dev)
+    with pytest.raises(ValueError):
+        GraphedForward(m)                                   # still in train mode
+    m.eval()
+    fast = GraphedForward(m)
+    for seed in (1, 2, 3):
+        for nb in (shape[0], 1):
+            x = make_input((nb,) + tuple(shape[1:]), seed=seed).to(dev)
+            with torch.no_grad():
+                ref = m(x)
+            got = fast(x).clone()
+            assert torch.equal(got, ref), (seed, nb, float((got - ref).abs().max()))
+    assert len(fast._graphs) == 2
+    with torch.no_grad():
+        m.fc.bias.add_(1.0)
+    fast.reset()
+    x = make_input(shape, seed=1).to(dev)
+    with torch.no_grad():
+        assert torch.equal(fast(x), m(x))
+    feat = GraphedForward(m, method='extract_feature')
+    with torch.no_grad():
+        a, b = m.extract_feature(x)
+    fa, fb = feat(x)
+    assert torch.equal(fa, a) and torch.equal(fb, b)
