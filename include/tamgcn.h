@@ -66,7 +66,7 @@ const char* tamgcn_last_kernel(void);
 int         tamgcn_get_split_mode(void);
 int         tamgcn_set_split_mode(int mode);
 /* Opt-in (initial value from TAMGCN_SPLIT3_FWD, default 0): with split mode >= 1 the FORWARD 1x1 convolutions into >= 128
- * channels run as a three-term bf16 split (six v_mfma_f32_16x16x32_bf16 per K = 32 step: hh, hm, mh, hl, lh, mm), which
+ * channels and the fused CTRGC forward's x3 GEMM (V = 20, Cin % 32 == 0) run as a three-term bf16 split (six v_mfma_f32_16x16x32_bf16 per K = 32 step: hh, hm, mh, hl, lh, mm), which
  * reproduces the fp32 product to ~1.2e-7 relative (outputs within 1e-6 of the exact kernels, tools/split3_check.py). */
 int         tamgcn_set_split3_fwd(int on);
 /* Opt-in (initial value from TAMGCN_ROWS128, default 0): forward 1x1 convolutions into >= 128 channels whose operand

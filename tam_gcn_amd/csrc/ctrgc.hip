@@ -319,7 +319,7 @@ __global__ __launch_bounds__(512) void ctrgc_E_kernel(const EArgs a) {
 // x3 tile for frames [t0, t0+bt): X3[(s*16+c)*PX3 + tl*V + v] = (W3_s x)[c0+c] + b3
 // The staging buffers alias the X3 tile (they are dead before the tile is written).
 // ---------------------------------------------------------------------------
-template <class G, int ST, bool SPL>
+template <class G, int ST, int SPL>   // SPL: 0 exact fp32-input MFMA, 2 / 3 = two- / three-term bf16 split
 __device__ void x3_chunk(const CtrgcArgs& a, int n, int c0, int t0, int bt, float* X3) {
     constexpr int V = G::V, NT = G::NT, CW = G::CW, NPF = G::NPF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -403,7 +403,7 @@ __device__ void x3_chunk(const CtrgcArgs& a, int n, int c0, int t0, int bt, floa
         if (k0 + SBK < a.Cin) prefetch(k0 + SBK);      // in flight under the MFMAs
         const float* at = As + j * SBKP + kq;
         const float* bt_ = Bs + kq * a.pitchB;
-        if constexpr (SPL) {
+        if constexpr (SPL != 0) {
             // split-fp32: the eight k = 4*k4 + kq this lane reads across the chunk form ONE K = 32 bf16 fragment
             static_assert(SBK == 32, "one K = 32 step per chunk");
             f32x4 a0[ST], a1[ST], b0[CW], b1[CW];
@@ -414,16 +414,30 @@ __device__ void x3_chunk(const CtrgcArgs& a, int n, int c0, int t0, int bt, floa
 #pragma unroll
                 for (int c = 0; c < CW; ++c) { b0[c][k4] = bt_[k4 * 4 * a.pitchB + bcol[c]]; b1[c][k4] = bt_[(k4 + 4) * 4 * a.pitchB + bcol[c]]; }
             }
-            bf16x8_t ah[ST], al[ST], bh[CW], bl[CW];
+            if constexpr (SPL == 3) {                   // hh, hm, mh, hl, lh, mm: the fp32 product to ~1.2e-7 relative
+                bf16x8_t ah[ST], am[ST], al[ST];
 #pragma unroll
-            for (int s = 0; s < ST; ++s) split_bf16x8(a0[s], a1[s], ah[s], al[s]);
+                for (int s = 0; s < ST; ++s) split3_bf16x8(a0[s], a1[s], ah[s], am[s], al[s]);
 #pragma unroll
-            for (int c = 0; c < CW; ++c) split_bf16x8(b0[c], b1[c], bh[c], bl[c]);
+                for (int c = 0; c < CW; ++c) {
+                    if (BAL && c == 2 && !third) continue;  // wave-uniform
+                    bf16x8_t bh, bm, bl;
+                    split3_bf16x8(b0[c], b1[c], bh, bm, bl);
 #pragma unroll
-            for (int c = 0; c < CW; ++c) {
-                if (BAL && c == 2 && !third) continue;  // wave-uniform
+                    for (int s = 0; s < ST; ++s) acc[s][c] = mfma_split3(ah[s], am[s], al[s], bh, bm, bl, acc[s][c]);
+                }
+            } else {
+                bf16x8_t ah[ST], al[ST], bh[CW], bl[CW];
 #pragma unroll
-                for (int s = 0; s < ST; ++s) acc[s][c] = mfma_split(ah[s], al[s], bh[c], bl[c], acc[s][c]);
+                for (int s = 0; s < ST; ++s) split_bf16x8(a0[s], a1[s], ah[s], al[s]);
+#pragma unroll
+                for (int c = 0; c < CW; ++c) split_bf16x8(b0[c], b1[c], bh[c], bl[c]);
+#pragma unroll
+                for (int c = 0; c < CW; ++c) {
+                    if (BAL && c == 2 && !third) continue;  // wave-uniform
+#pragma unroll
+                    for (int s = 0; s < ST; ++s) acc[s][c] = mfma_split(ah[s], al[s], bh[c], bl[c], acc[s][c]);
+                }
             }
         } else {
 #pragma unroll
@@ -562,7 +576,7 @@ struct DyTile {
 // ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
-template <class G, int ST, bool SPL>
+template <class G, int ST, int SPL>   // SPL: 0 exact fp32-input MFMA, 2 / 3 = two- / three-term bf16 split
 __device__ __forceinline__ void ctrgc_fwd_body(const CtrgcArgs& a, float* y, float* stats_part, float* x3_out) {
     constexpr int V = G::V, TB = G::TB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -648,11 +662,16 @@ __device__ __forceinline__ void ctrgc_fwd_body(const CtrgcArgs& a, float* y, flo
 
 template <class G, int ST>
 __global__ __launch_bounds__(G::NT) void ctrgc_fwd_kernel(const CtrgcArgs a, float* y, float* stats_part, float* x3_out) {
-    ctrgc_fwd_body<G, ST, false>(a, y, stats_part, x3_out);      // exact fp32-input MFMA
+    ctrgc_fwd_body<G, ST, 0>(a, y, stats_part, x3_out);          // exact fp32-input MFMA
 }
 template <class G, int ST>
 __global__ __launch_bounds__(G::NT) void ctrgc_fwd_split_kernel(const CtrgcArgs a, float* y, float* stats_part, float* x3_out) {
-    ctrgc_fwd_body<G, ST, true>(a, y, stats_part, x3_out);       // x3 GEMM as split-fp32 on the bf16 matrix cores
+    ctrgc_fwd_body<G, ST, 2>(a, y, stats_part, x3_out);          // x3 GEMM as two-term split-fp32 on the bf16 matrix cores
+}
+
+template <class G, int ST>
+__global__ __launch_bounds__(G::NT) void ctrgc_fwd_split3_kernel(const CtrgcArgs a, float* y, float* stats_part, float* x3_out) {
+    ctrgc_fwd_body<G, ST, 3>(a, y, stats_part, x3_out);          // three-term split: fp32-exact to rounding (opt-in, TAMGCN_SPLIT3_FWD)
 }
 
 // ---------------------------------------------------------------------------
@@ -759,7 +778,7 @@ __global__ __launch_bounds__(G::NT) void ctrgc_bwd_de_kernel(const CtrgcArgs a, 
     for (int t0 = 0; t0 < a.T; t0 += G::BT) {
         const int bt = min(G::BT, a.T - t0);
         dyt.load(dy, n, c0, a.T, t0, bt);              // in flight under the x3 GEMM below
-        x3_chunk<G, ST, false>(a, n, c0, t0, bt, X3);  // begins with a barrier: previous chunk fully consumed
+        x3_chunk<G, ST, 0>(a, n, c0, t0, bt, X3);  // begins with a barrier: previous chunk fully consumed
         dyt.commit(dy, Zs);
         __syncthreads();
         if (owner) {
@@ -1022,6 +1041,7 @@ extern "C" int tamgcn_ctrgc_fwd(const tamgcn_ctrgc_desc* d, float* y, float* sta
     // rounding noise, flips correspondingly more ReLU masks, and end-to-end gradients then differ from the reference
     // by ~1 % in places (tests/test_gpu_model.py strict case) although every tensor of the forward stays within 5e-6.
     if (tamgcn_split_mode() >= 2) CTRGC_DISPATCH(ctrgc_fwd_split_kernel, a, y, stats_part, x3_out);
+    else if (tamgcn_split3_fwd() && d->Cin % 32 == 0) CTRGC_DISPATCH(ctrgc_fwd_split3_kernel, a, y, stats_part, x3_out);
     else CTRGC_DISPATCH(ctrgc_fwd_kernel, a, y, stats_part, x3_out);
     TG_LAUNCH_CHECK("tamgcn_ctrgc_fwd");
     return 0;

@@ -438,6 +438,21 @@ def test_three_term_split_forward_gemm_matches_exact_kernels():
             assert e128 <= max(2.0 * e64, 2e-6 * float(ref.abs().max())), (e64, e128)
             assert float((y0 - y2).abs().max()) <= 2e-6 * float(y0.abs().max())
             assert float((p0.sum(2) - p2.sum(2)).abs().max()) <= 2e-6 * float(p0.sum(2).abs().max())
+        # the fused CTRGC forward's x3 GEMM takes the same three-term form under the switch (V = 20, Cin % 32 == 0)
+        N, Cin, Cout, T, V, S_, R = 3, 64, 64, 16, 20, 3, 8
+        x, pq = r(N, Cin, T, V), r(S_ * 2 * R, N, V)
+        W3, B3, W4, B4 = r(S_ * Cout, Cin) * Cin ** -0.5, r(S_ * Cout) * 0.1, r(S_, Cout, R) * R ** -0.5, r(S_, Cout) * 0.1
+        A, al = r(S_, V, V) * 0.3, torch.tensor([0.7], device=dev)
+        outs = []
+        for on in (0, 1):
+            lib.tamgcn_set_split_mode(1); lib.tamgcn_set_split3_fwd(on)
+            y, part, x3 = ops.ctrgc_fwd(S(x), pq, W3, B3, W4, B4, A, al, Cin, Cout, S_, R, stats=True, keep_x3=True)
+            assert (b'ctrgc_fwd_split3_kernel' in lib.tamgcn_last_kernel()) == bool(on), lib.tamgcn_last_kernel()
+            outs.append((y, part, x3))
+        (y0, p0, x30), (y1, p1, x31) = outs
+        assert float((x30 - x31).abs().max()) <= 2e-6 * float(x30.abs().max())
+        assert float((y0 - y1).abs().max()) <= 2e-6 * float(y0.abs().max())
+        assert float((p0.sum(2) - p1.sum(2)).abs().max()) <= 2e-6 * float(p0.sum(2).abs().max())
     finally:
         lib.tamgcn_set_split3_fwd(0)
         lib.tamgcn_set_rows128(0)
