@@ -438,3 +438,50 @@ def test_graphed_forward_replays_the_eval_path(golden_models):
         a, b = m.extract_feature(x)
     fa, fb = feat(x)
     assert torch.equal(fa, a) and torch.equal(fb, b)
+
+
+def test_backward_through_eval_mode_matches_the_oracle(golden_models):
+    """Gradients through the model in eval() mode (running statistics, no updates) -- the cross-modal caller fine-tunes a
+    head on top of the backbone's features with autograd on (models/resnet_gcn_attention.py:82-85): the input gradient and
+    every parameter gradient against the CPU oracle evaluated in fp64 with the fixture's running statistics, and the
+    buffers must stay untouched."""
+    from oracle import ctrgcn_oracle as O
+    tag, margs, shape = next(c for c in MODEL_CASES if c[0] == 'ucla_t13')
+    dev = torch.device('cuda:0')
+    m = M.Model(**margs)
+    fill_state_(m.state_dict(), seed=MODEL_PARAM_SEED)
+    sd0 = m.state_dict()
+    with torch.no_grad():
+        for k in sd0:
+            if 'running_' in k:
+                sd0[k].copy_(torch.from_numpy(golden_models[f'{tag}/evalbuf/{k}']))
+    sd = {k: (v.detach().clone().double() if v.is_floating_point() else v.clone()) for k, v in m.state_dict().items()}
+    pkeys = [k for k, _ in m.named_parameters()]
+    for k in pkeys:
+        sd[k].requires_grad_(True)
+    xo = make_input(shape, seed=MODEL_X_SEED).double().requires_grad_(True)
+    cot = make_input((shape[0], margs['num_class']), seed=77).double()
+    lo = O.model_forward(xo, sd, margs['num_point'], training=False)
+    (lo * cot).sum().backward()
+    m = m.to(dev).eval()
+    before = {k: b.detach().clone() for k, b in m.named_buffers()}
+    x = make_input(shape, seed=MODEL_X_SEED).to(dev).requires_grad_(True)
+    lg = m(x)
+    (lg * cot.float().to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    rel = lambda a, b: float((a.detach().cpu().double() - b).abs().max() / (b.abs().max() + 1e-30))   # noqa: E731
+    assert rel(lg, lo.detach()) <= 1e-5
+    assert rel(x.grad, xo.grad) <= 2e-4, rel(x.grad, xo.grad)
+    worst = []
+    for k, p in m.named_parameters():
+        ref = sd[k].grad
+        assert p.grad is not None, k
+        if float(ref.abs().max()) < 1e-12:
+            assert float(p.grad.abs().max()) < 1e-6, k
+            continue
+        e = rel(p.grad, ref)
+        if e > (5e-4 if p.numel() > 1 else 2e-3):
+            worst.append((k, e))
+    assert not worst, worst[:10]
+    for k, b in m.named_buffers():
+        assert torch.equal(b, before[k]), f'{k} changed in eval mode'
