@@ -485,3 +485,51 @@ def test_backward_through_eval_mode_matches_the_oracle(golden_models):
     assert not worst, worst[:10]
     for k, b in m.named_buffers():
         assert torch.equal(b, before[k]), f'{k} changed in eval mode'
+
+
+def test_non_adaptive_graph_and_dropout_head():
+    """Model(adaptive=False): the adjacency is a constant of each unit_gcn, not a parameter (reference models/ctrgcn.py:225-228,
+    248-251) -- state dict without PA keys, logits / input gradient / parameter gradients against the oracle fed the same
+    constant; drop_out > 0 takes the reference's own pooling + nn.Dropout + fc route (:343-348): identical to the fused
+    head in eval mode, runs and back-propagates in train mode."""
+    from oracle import ctrgcn_oracle as O
+    margs = dict(MODEL_CASES[0][1], adaptive=False)
+    shape = (3, 3, 16, 20, 1)
+    dev = torch.device('cuda:0')
+    m = M.Model(**margs)
+    fill_state_(m.state_dict(), seed=MODEL_PARAM_SEED)
+    assert not any(k.endswith('PA') for k in m.state_dict()) and len(m.state_dict()) == 892 - 10
+    sd = {k: (v.detach().clone().double() if v.is_floating_point() else v.clone()) for k, v in m.state_dict().items()}
+    for i in range(1, 11):
+        sd[f'l{i}.gcn1.PA'] = getattr(m, f'l{i}').gcn1.A.double().clone()
+    for k, _ in m.named_parameters():
+        sd[k].requires_grad_(True)
+    xo = make_input(shape, seed=5).double().requires_grad_(True)
+    lab = make_labels(shape[0], margs['num_class'], seed=6)
+    lo = O.model_forward(xo, sd, margs['num_point'], training=True)
+    torch.nn.functional.cross_entropy(lo, lab).backward()
+    m = m.to(dev).train()
+    x = make_input(shape, seed=5).to(dev).requires_grad_(True)
+    lg = m(x)
+    torch.nn.functional.cross_entropy(lg, lab.to(dev)).backward()
+    torch.cuda.synchronize()
+    rel = lambda a, b: float((a.detach().cpu().double() - b.detach()).abs().max() / (b.detach().abs().max() + 1e-30))   # noqa: E731
+    assert rel(lg, lo) <= 1e-4
+    assert rel(m.fc.weight.grad, sd['fc.weight'].grad) <= 1e-3
+    assert rel(m.l1.gcn1.convs[0].conv3.weight.grad, sd['l1.gcn1.convs.0.conv3.weight'].grad) <= 5e-2    # through ten blocks of ReLU masks
+    assert getattr(m.l1.gcn1, 'A').device.type == 'cuda' and not m.l1.gcn1.A.requires_grad
+    # drop_out > 0: torch's own head
+    md = M.Model(**dict(MODEL_CASES[0][1], drop_out=0.5))
+    fill_state_(md.state_dict(), seed=MODEL_PARAM_SEED)
+    m0 = M.Model(**MODEL_CASES[0][1])
+    m0.load_state_dict(md.state_dict())
+    md, m0 = md.to(dev).eval(), m0.to(dev).eval()
+    xe = make_input(shape, seed=7).to(dev)
+    with torch.no_grad():
+        a, b = md(xe), m0(xe)
+    assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-6
+    md.train()
+    xt = make_input(shape, seed=8).to(dev).requires_grad_(True)
+    out = md(xt)
+    out.sum().backward()
+    assert out.shape == (shape[0], margs['num_class']) and torch.isfinite(xt.grad).all() and md.fc.weight.grad is not None
