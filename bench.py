@@ -23,6 +23,7 @@ JSON line.  Besides the throughput it reports
                  host cores, bounded to ~20 s.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -250,11 +251,11 @@ def _log(msg):
 _T0 = time.perf_counter()
 
 
-def cpu_baseline(budget_s=24.0):
+def cpu_baseline():
     """The oracle (kind 'port': our stock-PyTorch restatement, pinned to the reference by tests/golden) on the host
     cores, forward + CE + backward (optimizer step excluded).  `value` is the leg with the GPU line's
     own workload (batch 256, T = 64); the reference's batch size (16, config/nucla/gcn.yaml:37) and real clip length
-    (T = 52, feeder/feeder_nucla_gcn.py:26) are reported beside it.  Bounded: about `budget_s` seconds in all."""
+    (T = 52, feeder/feeder_nucla_gcn.py:26) are reported beside it.  Bounded: fixed step counts, ~1.5 min on a 16-thread share."""
     from oracle import ctrgcn_oracle as O
     from tam_gcn_amd.models.ctrgcn import Model
     cores = host_cores()
@@ -265,7 +266,7 @@ def cpu_baseline(budget_s=24.0):
     sd = O.clone_state(m.state_dict(), requires_grad=True)
     params = [v for v in sd.values() if v.requires_grad]
 
-    def leg(B, T, budget, max_steps):
+    def leg(B, T, warm, timed):
         g = torch.Generator().manual_seed(1234)
         x = torch.rand(B, 3, T, V_JOINTS, 1, generator=g) * 2 - 1
         lab = torch.randint(0, 10, (B,), generator=g)
@@ -275,19 +276,21 @@ def cpu_baseline(budget_s=24.0):
                 p.grad = None
             torch.nn.functional.cross_entropy(O.model_forward(x, sd, 20, training=True), lab).backward()
 
-        t0 = time.perf_counter(); step(); t1 = time.perf_counter() - t0
-        n = max(1, min(max_steps, int(budget / max(t1, 1e-3))))
+        for _ in range(warm):
+            step()
         t0 = time.perf_counter()
-        for _ in range(n):
+        for _ in range(timed):
             step()
         dt = time.perf_counter() - t0
-        _log(f'cpu baseline: B={B} T={T}: {n} steps in {dt:.1f}s on {cores} threads')
-        return dict(batch=B, T=T, clips_per_s=B * n / dt, steps=n, seconds=round(dt, 2))
+        _log(f'cpu baseline: B={B} T={T}: {timed} steps in {dt:.1f}s after {warm} warm-up on {cores} threads')
+        return dict(batch=B, T=T, clips_per_s=B * timed / dt, steps=timed, warmup=warm, seconds=round(dt, 2))
 
-    legs = [leg(16, T_FRAMES, budget_s * 0.2, 24), leg(16, 52, budget_s * 0.15, 24), leg(PER_GPU_BATCH, T_FRAMES, budget_s * 0.45, 3)]
+    # 3 warm-up + >= 5 timed steps at the reference's batch size; the bench workload's own batch (256)
+    # costs ~17 s per step on a 16-thread share, so it gets 2 warm-up + 3 timed (what bounds this function's run time)
+    legs = [leg(16, T_FRAMES, 3, 8), leg(16, 52, 3, 8), leg(PER_GPU_BATCH, T_FRAMES, 2, 3)]
     main_leg = legs[2]
     return dict(value=main_leg['clips_per_s'], unit='clips/s', cores=torch.get_num_threads(), kind='port',
-                sample=f"{main_leg['steps']} steps of batch {PER_GPU_BATCH} (T=64,V=20) fwd+CE+bwd after 1 warm-up, "
+                sample=f"{main_leg['steps']} steps of batch {PER_GPU_BATCH} (T=64,V=20) fwd+CE+bwd after {main_leg['warmup']} warm-up, "
                        f"{main_leg['seconds']}s; optimizer step excluded",
                 legs=legs)
 
@@ -328,6 +331,9 @@ def main():
     ap.add_argument('--batch', type=int, default=None, help='clips per GPU (per stream); default 256, 128 for --config 4stream')
     ap.add_argument('--config', choices=('ucla', '4stream'), default='ucla')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--fork-streams', type=int, default=None,
+                    help='4stream: 1 = every model on its own HIP stream (forward and, through autograd, backward), 0 = one after '
+                         'the other on one stream; default 1')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -378,7 +384,7 @@ def main():
         models.append(m)
     models = models.to(dev).train()
     arena = ParamArena(models)                            # every model's parameters in ONE flat buffer ...
-    broadcast_state(models)
+    broadcast_state(models, arena=arena)                  # one broadcast of the arena + one per dtype of packed buffers
     bucket = arena.grad_bucket()                          # ... and ONE congruent gradient bucket: one all-reduce per step
     opt = SGDNesterov(arena.params, lr=0.01, momentum=0.9, weight_decay=1e-4, arena=arena, bucket=bucket)
     g = torch.Generator().manual_seed(1234 + rank)
@@ -399,12 +405,25 @@ def main():
         from tam_gcn_amd.functional import CrossEntropyLoss
         ce = CrossEntropyLoss()                             # the harness's nn.CrossEntropyLoss() as two HIP launches (row f1)
 
+        fork = four and (args.fork_streams is None or bool(args.fork_streams))
+        model_streams = [torch.cuda.Stream(dev) for _ in streams] if fork else []
+
         def fwd_bwd():
             bucket.zero()
             total = None
-            for name, m in zip(streams, models):          # the streams are derived on the GPU from the resident joint clips
-                xs = x if name == 'joint' else _ops.stream_derive(x, parent, name)
-                loss = ce(m(xs), lab)
+            cur = torch.cuda.current_stream(dev)
+            losses = []
+            for i, (name, m) in enumerate(zip(streams, models)):   # the streams are derived on the GPU from the resident joint clips
+                ctx = contextlib.nullcontext()
+                if fork:                                  # the four models are independent until the bucket: one HIP stream each.
+                    model_streams[i].wait_stream(cur)     # Autograd replays every node on the stream of its forward and joins
+                    ctx = torch.cuda.stream(model_streams[i])    # the leaf streams into `cur` when backward() returns.
+                with ctx:
+                    xs = x if name == 'joint' else _ops.stream_derive(x, parent, name)
+                    losses.append(ce(m(xs), lab))
+            for st in model_streams:
+                cur.wait_stream(st)
+            for loss in losses:
                 total = loss if total is None else total + loss
             total.backward()
             bucket.pack()
@@ -523,13 +542,19 @@ def main():
             roof, shares = roofline_of(agg)
             layer_rows = ctrgc_layer_table(layers)
     if rank == 0:
-        cpu = None if (args.no_cpu_baseline or world > 1 or rehearsal) else cpu_baseline()
+        if args.no_cpu_baseline or world > 1 or rehearsal:
+            cpu = None
+            cpu_why = ('--no-cpu-baseline' if args.no_cpu_baseline else 'rehearsal' if rehearsal else
+                       'timed on rank 0 of the N = 1 run only (the host cores are shared by the N ranks here)')
+        else:
+            cpu, cpu_why = cpu_baseline(), None
         split = str(split)
         clips = world * B * args.steps * len(streams)
         out = {
             'metric': 'skeleton clips/sec (fwd+CE+bwd+grad all-reduce+SGD step), N-UCLA 20-joint x 64-frame',
             'value': None if rehearsal else clips / dt, 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'ms_per_step_exact_f32': ms_exact, 'higher_is_better': True,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'ms_per_step_exact_f32': ms_exact,
+            'value_exact_f32': None if (ms_exact is None or rehearsal) else world * B * len(streams) / (ms_exact * 1e-3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
             'dtype': {'0': 'f32 (exact fp32-input MFMA in every GEMM, TAMGCN_SPLIT_BF16=0)',
                       '1': 'f32 (fwd GEMMs exact fp32-input MFMA; bwd weight-gradient and C>=128 data-gradient GEMMs 2-term '
@@ -542,7 +567,8 @@ def main():
                                    ' fwd+CE+bwd+grad-allreduce+SGD step, train-mode BN',
                        'global_batch': world * B, 'streams': len(streams), 'parallelism': f'dp{world}', 'launch': mode,
                        'final_loss': final_loss, 'rehearsal': rehearsal},
-            'roofline': roof, 'cpu_baseline': cpu, 'ctrgc_fwd_layers': layer_rows, 'abi_ms_per_2_steps': shares,
+            'roofline': roof, 'cpu_baseline': cpu, 'cpu_baseline_absent_because': cpu_why, 'ctrgc_fwd_layers': layer_rows,
+            'abi_ms_per_2_steps': shares,
         }
     if world > 1:
         dist.barrier()

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TAMGCN_VERSION 100          /* 0.1.0 */
+#define TAMGCN_VERSION 300          /* round 3: bumped on every change of a struct layout, signature or documented semantics */
 #define TAMGCN_MAX_SUBSETS 3
 #define TAMGCN_MAX_V 32             /* joints supported by the LDS-resident CTRGC tiles (V in {20, 25}); V in {32, 64}: tamgcn_ctrgc_tiled_* */
 
@@ -353,10 +353,14 @@ int tamgcn_head_fc_fwd(const float* pooled, const float* W, const float* b, int 
 int tamgcn_head_fc_bwd(const float* dlogits, const float* pooled, const float* W, int N, int C, int K,
                        float* dW, float* db, float* dpooled, void* stream);
 
-/* ---- loss of the harness step (nn.CrossEntropyLoss(), reduction 'mean': reference processor/recognition_rgb.py:19, :62) ----
- * _ce_fwd  loss[0] = mean_n (logsumexp(logits[n]) - logits[n][labels[n]]); g (N, K) = softmax - onehot (kept for the backward);
- *          labels int64 on the device, every label in [0, K).  One launch (aten: log_softmax + nll_loss).
- * _ce_bwd  dlogits = g * dloss[0] / N   (aten: nll_loss_backward + log_softmax_backward). */
+/* ---- loss of the harness step (nn.CrossEntropyLoss(), reduction 'mean', ignore_index -100: reference
+ *      processor/recognition_rgb.py:19, :62) ----
+ * _ce_fwd  loss[0] = mean over the KEPT rows of (logsumexp(logits[n]) - logits[n][labels[n]]); g (N, K) = (softmax - onehot) / kept
+ *          (kept for the backward).  labels int64 on the device: a row labelled -100 (torch's default ignore_index) is skipped
+ *          -- zero gradient, not counted; the loss is NaN when no row is kept, as torch's is.  Any other label outside
+ *          [0, K), where torch raises a device assert, makes loss[0] NaN and zeroes that row of g; nothing outside the
+ *          row is read.  One launch (aten: log_softmax + nll_loss).
+ * _ce_bwd  dlogits = g * dloss[0]   (aten: nll_loss_backward + log_softmax_backward). */
 int tamgcn_ce_fwd(const float* logits, const long long* labels, int N, int K, float* loss, float* g, void* stream);
 int tamgcn_ce_bwd(const float* g, const float* dloss, int N, int K, float* dlogits, void* stream);
 
@@ -364,7 +368,10 @@ int tamgcn_ce_bwd(const float* g, const float* dloss, int N, int K, float* dlogi
  * fused (N, K) = sum_s weights[s] * scores[s]  (softmax = 0: reference ensemble/ensemble_resnet_ctrgcn.py:50-54, score_a + alpha * score_b)
  *             or sum_s weights[s] * softmax_k(scores[s])  (softmax = 1: ensemble/ensemble_ctrgcn_resnet_eval.py:99-106);
  * pred (N) int64 = first arg max over k (numpy.argmax); class_stats NULL | int32 [K][2] = (correct, total) per true class
- * (compute_accuracy, ensemble_ctrgcn_resnet_eval.py:217-234), needs labels (N) int64.  scores is [S][N][K] contiguous. */
+ * (compute_accuracy, ensemble_ctrgcn_resnet_eval.py:217-234), needs labels (N) int64; a label outside [0, K) belongs to no
+ * class row and is left out of every (correct, total) pair (the scripts' labels come from the split lists and are always
+ * in range; their overall accuracy divides by len(labels) -- the Python layer does the same and raises on such a label).
+ * scores is [S][N][K] contiguous. */
 int tamgcn_score_fuse(const float* scores, const float* weights, int S, int N, int K, int softmax,
                       const long long* labels, float* fused, long long* pred, int* class_stats, void* stream);
 

@@ -131,6 +131,7 @@ class TamgcnLibraryError(RuntimeError):
 
 
 _lib = None
+ABI_VERSION = 300          # include/tamgcn.h TAMGCN_VERSION this binding's structs and signatures were written for
 
 
 def load():
@@ -157,6 +158,11 @@ def load():
             raise TamgcnLibraryError(f'{path} does not export {name}') from e
         fn.restype = res
         fn.argtypes = args
+    got = lib.tamgcn_version()
+    if got != ABI_VERSION:                             # a stale or side-built library with the same symbol set would be
+        raise TamgcnLibraryError(                      # called with the wrong struct layouts and corrupt device memory
+            f'{path} reports ABI version {got}, this binding is written for {ABI_VERSION}: rebuild with '
+            '`python -m tam_gcn_amd.build --force`')
     _lib = lib
     return lib
 

@@ -111,22 +111,49 @@ __global__ __launch_bounds__(SH_NT) void fc_bwd_kernel(const float* dl, const fl
     }
 }
 
-// ---- cross-entropy over the logits (nn.CrossEntropyLoss, reduction 'mean': reference processor/recognition_rgb.py:19, :62) ----
+// ---- cross-entropy over the logits (nn.CrossEntropyLoss with its default arguments, reduction 'mean', ignore_index -100:
+// reference processor/recognition_rgb.py:19, :62) ----
 // ONE workgroup: thread -> samples n = tid, tid + 256, ...; per sample lse by max-shift, the loss term, and
-// g[n][k] = softmax_k - [k == y_n] (the backward only scales it).  Terms are summed in fp64 in a fixed order.
+// g[n][k] = (softmax_k - [k == y_n]) / kept (the backward only scales it by dloss).  Rows labelled ignore_index are
+// skipped (zero gradient, not counted: the mean is over the kept rows, NaN when none is kept, as torch gives).  Any
+// other label outside [0, K) -- torch raises a device assert there -- makes the loss NaN and zeroes that row's gradient;
+// no memory outside the row is touched.  Terms are summed in fp64 in a fixed order.
+constexpr long long CE_IGNORE_INDEX = -100;
 __global__ __launch_bounds__(SH_NT) void ce_fwd_kernel(const float* logits, const long long* labels, int N, int K, float* loss, float* g) {
     __shared__ double red[SH_NT];
+    __shared__ int cnt[SH_NT];
+    __shared__ int bad[SH_NT];
+    int kept = 0, nbad = 0;
+    for (int n = threadIdx.x; n < N; n += SH_NT) {
+        const long long y = labels[n];
+        if (y >= 0 && y < K) ++kept;
+        else if (y != CE_IGNORE_INDEX) ++nbad;
+    }
+    cnt[threadIdx.x] = kept;
+    bad[threadIdx.x] = nbad;
+    __syncthreads();
+    for (int o = SH_NT / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { cnt[threadIdx.x] += cnt[threadIdx.x + o]; bad[threadIdx.x] += bad[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    kept = cnt[0];
+    nbad = bad[0];
+    const float invk = kept > 0 ? 1.f / (float)kept : 0.f;
     double acc = 0.0;
     for (int n = threadIdx.x; n < N; n += SH_NT) {
         const float* l = logits + (long long)n * K;
+        const long long y = labels[n];
+        if (y < 0 || y >= K) {
+            for (int k = 0; k < K; ++k) g[(long long)n * K + k] = 0.f;
+            continue;
+        }
         float m = l[0];
         for (int k = 1; k < K; ++k) m = fmaxf(m, l[k]);
         float s = 0.f;
         for (int k = 0; k < K; ++k) s += expf(l[k] - m);
         const float lse = m + logf(s);
-        const long long y = labels[n];
         const float inv = 1.f / s;
-        for (int k = 0; k < K; ++k) g[(long long)n * K + k] = expf(l[k] - m) * inv - (k == y ? 1.f : 0.f);
+        for (int k = 0; k < K; ++k) g[(long long)n * K + k] = (expf(l[k] - m) * inv - (k == y ? 1.f : 0.f)) * invk;
         acc += (double)(lse - l[y]);
     }
     red[threadIdx.x] = acc;
@@ -135,7 +162,7 @@ __global__ __launch_bounds__(SH_NT) void ce_fwd_kernel(const float* logits, cons
         if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) loss[0] = (float)(red[0] / (double)N);
+    if (threadIdx.x == 0) loss[0] = (nbad || kept == 0) ? __builtin_nanf("") : (float)(red[0] / (double)kept);
 }
 
 __global__ __launch_bounds__(SH_NT) void ce_bwd_kernel(const float* g, const float* dloss, int total, float scale, float* dlogits) {
@@ -250,7 +277,7 @@ extern "C" int tamgcn_ce_fwd(const float* logits, const long long* labels, int N
 extern "C" int tamgcn_ce_bwd(const float* g, const float* dloss, int N, int K, float* dlogits, void* stream) {
     TG_CHECK(g && dloss && dlogits && N > 0 && K > 0, "tamgcn_ce_bwd: bad args");
     const int total = N * K;
-    hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)ceil_div(total, SH_NT)), dim3(SH_NT), 0, (hipStream_t)stream, g, dloss, total, 1.f / (float)N, dlogits);
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)ceil_div(total, SH_NT)), dim3(SH_NT), 0, (hipStream_t)stream, g, dloss, total, 1.f, dlogits);   // g carries 1 / kept already
     tamgcn_note_kernel("ce_bwd_kernel");
     TG_LAUNCH_CHECK("tamgcn_ce_bwd");
     return 0;

@@ -131,12 +131,33 @@ class FlatGradBucket:
         return self.flat
 
 
-def broadcast_state(module, src=0, group=None):
-    """Make every replica start from rank ``src``'s parameters and buffers."""
+def broadcast_state(module, src=0, group=None, arena=None):
+    """Make every replica start from rank ``src``'s parameters and buffers.
+
+    A handful of collectives instead of one per tensor (892 for the N-UCLA model): with ``arena`` (a ParamArena over
+    this module) its flat buffer goes in ONE broadcast; everything else -- frozen parameters, BatchNorm running
+    statistics, ``num_batches_tracked`` counters -- is packed per dtype into one flat tensor, broadcast, and copied back
+    in place (two more broadcasts: fp32 and int64)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
-    for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src, group=group)
+    rest = list(module.parameters()) + list(module.buffers())
+    if arena is not None:
+        if not arena.intact():
+            raise ValueError('broadcast_state: the ParamArena no longer backs the parameters')
+        dist.broadcast(arena.flat, src=src, group=group)
+        inside = {id(p) for p in arena.params}
+        rest = [t for t in rest if id(t) not in inside]
+    by_type = {}
+    for t in rest:
+        by_type.setdefault((t.dtype, t.device), []).append(t.data)
+    with torch.no_grad():
+        for ts in by_type.values():
+            flat = torch.cat([t.reshape(-1) for t in ts])
+            dist.broadcast(flat, src=src, group=group)
+            off = 0
+            for t in ts:
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
 
 
 def shard_batch(n_global, rank, world):

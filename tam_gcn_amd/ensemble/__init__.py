@@ -31,6 +31,8 @@ def fuse(scores, weights, softmax=False, labels=None):
         lab = torch.as_tensor(np.asarray(labels) if not torch.is_tensor(labels) else labels).to(dev, torch.int64).contiguous()
         if lab.shape != (st.shape[1],):
             raise ValueError('fuse: one label per sample')
+        if bool(((lab < 0) | (lab >= st.shape[2])).any()):         # the kernel would leave it out of every class row, while
+            raise ValueError('fuse: label outside [0, K)')         # the scripts' accuracy divides by len(labels)
     return ops.score_fuse(st, w, softmax, lab)
 
 

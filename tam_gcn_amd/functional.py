@@ -36,17 +36,46 @@ KEEP_X3 = os.environ.get('TAMGCN_KEEP_X3', '1') != '0'
 GLOBAL_E = os.environ.get('TAMGCN_GLOBAL_E', '1') != '0'
 
 
+def _side_streams(device, main, k):
+    """The k side streams that belong to MAIN stream `main` of `device`.
+
+    The pool is keyed by the main stream, not only by the device: a tensor allocated while side stream S is current
+    belongs to S's block pool in torch's caching allocator and is handed out again to the next allocation on S as soon
+    as Python drops it.  That is safe only if S's next work is ordered after every consumer of the old tensor, which
+    fork() guarantees for consumers on the main stream S was forked from -- and for no other stream.  Two callers on
+    two main streams (four models on four streams, GraphedForward beside a training step, two DataParallel threads on
+    one device) therefore never share a side stream.  torch hands out streams from a pool of 32 per device that wraps
+    around; if a fresh stream aliases one already in use here, this main stream gets no side streams (its branches run
+    in order on the main stream): slower, never a race."""
+    key = (device.index, main.cuda_stream, k)
+    got = _SIDE.get(key)
+    if got is None:
+        with _SIDE_LOCK:
+            got = _SIDE.get(key)
+            if got is None:
+                taken = {main.cuda_stream}
+                for (d, m, _), ss in _SIDE.items():
+                    if d == device.index:
+                        taken.add(m)
+                        taken.update(s.cuda_stream for s in ss)
+                got = []
+                for _ in range(k):
+                    s = torch.cuda.Stream(device)
+                    if s.cuda_stream in taken:
+                        got = []
+                        break
+                    taken.add(s.cuda_stream)
+                    got.append(s)
+                _SIDE[key] = got
+    return got
+
+
 class Fork:
     """with Fork(device, k) as f:  f.on(i) -> context running on side stream i; joins on exit."""
 
     def __init__(self, device, k=2):
         self.main = torch.cuda.current_stream(device)
-        key = (device.index, k)                              # per device: nn.DataParallel drives each device from ONE thread at a time
-        if key not in _SIDE:
-            with _SIDE_LOCK:
-                if key not in _SIDE:
-                    _SIDE[key] = [torch.cuda.Stream(device) for _ in range(k)]
-        self.side = _SIDE[key] if USE_SIDE_STREAMS else []
+        self.side = _side_streams(device, self.main, k) if USE_SIDE_STREAMS else []
         self.used = set()
 
     def on(self, i):
@@ -106,8 +135,7 @@ class BN:
     def fwd(self, part, part_coff, count, training, coef, save, coff, batch=None):
         """batch (ops.BNBatch): only registered; batch.flush() launches it with the others."""
         if training:                                       # the kernel rewrites the running statistics through raw pointers:
-            d_ = self.m.__dict__                           # Tensor._version does not see it, the eval-coefficient cache must
-            d_['_tamgcn_epoch'] = d_.get('_tamgcn_epoch', 0) + 1
+            _bn_epoch(self.m)[0] += 1                      # Tensor._version does not see it, the eval-coefficient cache must
         if batch is not None:
             batch.fwd(part, part_coff, count, self.w, self.b, self.rm, self.rv, self.nbt, self.mom, self.eps, training, coef, save, coff, self.C)
             return
@@ -124,6 +152,24 @@ class BN:
         else:
             ops.bn_bwd_finalize(part, part_coff, count, self.w, save, save_coff, training, dg, db, dbias, coef, coff, self.C)
         return dg, db, dbias
+
+
+def _bn_epoch(m):
+    """One-element list counting the train-mode statistic updates of BatchNorm module `m`.  A mutable object, created
+    when the owning module is built (tag_batchnorms_), so that nn.DataParallel's replicas -- whose __dict__ is a shallow
+    copy of the original's -- share it: a replica's training step invalidates the original's eval-coefficient cache."""
+    ep = m.__dict__.get('_tamgcn_epoch')
+    if ep is None:
+        ep = m.__dict__['_tamgcn_epoch'] = [0]
+    return ep
+
+
+def tag_batchnorms_(module):
+    """Give every BatchNorm under `module` its update counter now (called at the end of the mirror modules' __init__)."""
+    for m in module.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            _bn_epoch(m)
+    return module
 
 
 def _coef(C_, like):
@@ -143,7 +189,7 @@ EVAL_FUSED = os.environ.get('TAMGCN_EVAL_FUSED', '1') != '0'
 
 def _eval_cached(owner, tag, bns, build):
     """build() -> value, cached on nn.Module `owner` under `tag` while the tensors of the BN views `bns` are unchanged."""
-    key = tuple((t.data_ptr(), t._version) for bn in bns for t in bn.tensors()) + tuple(bn.m.__dict__.get('_tamgcn_epoch', 0) for bn in bns)
+    key = tuple((t.data_ptr(), t._version) for bn in bns for t in bn.tensors()) + tuple(_bn_epoch(bn.m)[0] for bn in bns)
     cache = owner.__dict__.setdefault('_tamgcn_eval_cache', {})
     hit = cache.get(tag)
     if hit is not None and hit[0] == key:
@@ -843,7 +889,8 @@ class StGcnFn(_Fn):
     """relu(tcn(gcn(x, A)) + residual(x)) of one st_gcn block as one autograd node."""
 
     @staticmethod
-    def forward(ctx, mod, x, Ae, w3, b3, g1, be1, wt, bt, g2, be2, *res_params):
+    def forward(ctx, mod, tail, x, Ae, w3, b3, g1, be1, wt, bt, g2, be2, *res_params):
+        """tail False: stop at the second BatchNorm's output (no residual, no ReLU) -- st_gcn with an active Dropout."""
         N, Cin, T, V = x.shape
         Cout, s, kt = mod.out_channels, mod.stride, mod.t_kernel
         training = mod.training
@@ -864,9 +911,10 @@ class StGcnFn(_Fn):
         coef2, save2 = _coef(Cout, x)
         bn2.fwd(zpart, 0, cnt2, training, coef2, save2, 0)
         r_pre = coef_r = save_r = None
-        if mod._rmode == 'identity':
+        rmode = mod._rmode if tail else 'zero'
+        if rmode == 'identity':
             res = xs
-        elif mod._rmode == 'conv':
+        elif rmode == 'conv':
             wr, br = res_params[0], res_params[1]
             bnr = BN(mod.residual[1])
             r_pre, rpart = ops.conv(xs, K=Cin, w=wr, bias=br, M=Cout, KT=1, stride=s, pad=0, T_out=T2, stats=training)
@@ -875,10 +923,11 @@ class StGcnFn(_Fn):
             res = S(r_pre, coef=coef_r)
         else:
             res = None
-        out = ops.add_act_fwd(S(z_pre, coef=coef2), res, True, Cout)
+        out = ops.add_act_fwd(S(z_pre, coef=coef2), res, bool(tail), Cout)
         if save:
             ctx.sv = dict(x=x, Ae=Ae, W3=W3, b3=b3, a=a, x3=x3, y_pre=y_pre, z_pre=z_pre, r_pre=r_pre, out=out, coef1=coef1, save1=save1,
-                          coef2=coef2, save2=save2, coef_r=coef_r, save_r=save_r, wt=wt, res_params=res_params, training=training)
+                          coef2=coef2, save2=save2, coef_r=coef_r, save_r=save_r, wt=wt, res_params=res_params, training=training,
+                          rmode=rmode, tail=bool(tail))
         ctx.mod = mod
         return out
 
@@ -894,11 +943,15 @@ class StGcnFn(_Fn):
         T2 = z_pre.shape[2]
         cnt1, cnt2 = N * T * V, N * T2 * V
         pad = (kt - 1) // 2
-        need_dx = ctx.needs_input_grad[1]
+        need_dx = ctx.needs_input_grad[2]
+        rmode = sv['rmode']
         bn1, bn2 = BN(mod.tcn[0]), BN(mod.tcn[3])
         xs = S(x)
         with ops.ReduceBatch():
-            dz, part = ops.add_act_bwd(dout.contiguous(), out, 1, z_pre, sv['save2'], r_pre, sv['save_r'], want_dz=True)
+            dout = dout.contiguous()
+            dz, part = ops.add_act_bwd(dout, out, int(sv['tail']), z_pre, sv['save2'], r_pre, sv['save_r'], want_dz=sv['tail'])
+            if dz is None:
+                dz = dout
             coefb2 = torch.empty(3, Cout, device=x.device)
             dg2, dbe2, dbt = bn2.bwd(part, 0, cnt2, sv['save2'], 0, training, coefb2, 0, want_dbias=True)
             gz = S(dz, z_pre, coefb2)
@@ -915,9 +968,9 @@ class StGcnFn(_Fn):
             dw3 = ops.wgrad(S(dx3), xs, M=a['K'] * Cout, K=Cin)
             gres = []
             add1 = None
-            if mod._rmode == 'identity':
+            if rmode == 'identity':
                 add1 = dz
-            elif mod._rmode == 'conv':
+            elif rmode == 'conv':
                 wr = sv['res_params'][0]
                 bnr = BN(mod.residual[1])
                 coefb_r = torch.empty(3, Cout, device=x.device)
@@ -931,8 +984,8 @@ class StGcnFn(_Fn):
             dx = None
             if need_dx:
                 dx, _ = ops.conv(S(dx3), K=a['K'] * Cout, w=W3, bias=None, M=Cin, wmode=1, add1=add1)
-        dAe = dA.transpose(1, 2) if ctx.needs_input_grad[2] else None
-        return (None, dx, dAe, dw3.reshape(a['K'] * Cout, Cin, 1, 1), db3, dg1, dbe1, dwt, dbt, dg2, dbe2, *gres)
+        dAe = dA.transpose(1, 2) if ctx.needs_input_grad[3] else None
+        return (None, None, dx, dAe, dw3.reshape(a['K'] * Cout, Cin, 1, 1), db3, dg1, dbe1, dwt, dbt, dg2, dbe2, *gres)
 
 
 class PointwiseConvFn(_Fn):

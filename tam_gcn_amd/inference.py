@@ -39,7 +39,11 @@ class GraphedForward:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 out = fn(static_in)
-        return g, static_in, out
+        # The graph reads the eval path's folded BatchNorm coefficients through their pointers, and those tensors are
+        # owned by the per-module caches (functional._eval_cached): an eager forward after a parameter change evicts
+        # them.  This entry keeps them alive, so a replay without reset() reads stale coefficients, never freed memory.
+        keep = [dict(m.__dict__['_tamgcn_eval_cache']) for m in self.model.modules() if '_tamgcn_eval_cache' in m.__dict__]
+        return g, static_in, out, keep
 
     def __call__(self, x):
         if not x.is_cuda:
@@ -50,7 +54,7 @@ class GraphedForward:
             if len(self._graphs) >= self.max_shapes:
                 self._graphs.pop(next(iter(self._graphs)))
             ent = self._graphs[key] = self._capture(x)
-        g, static_in, out = ent
+        g, static_in, out, _ = ent
         static_in.copy_(x)
         g.replay()
         return out

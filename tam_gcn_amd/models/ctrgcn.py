@@ -120,6 +120,7 @@ class TemporalConv(nn.Module):
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=(kernel_size, 1), padding=(self.pad, 0),
                               stride=(stride, 1), dilation=(dilation, 1))
         self.bn = nn.BatchNorm2d(out_channels)
+        Fn.tag_batchnorms_(self)
 
     def forward(self, x):
         cfg = (self.kernel_size, self.stride, self.dilation, self.pad, self.bn)
@@ -137,6 +138,7 @@ class unit_tcn(nn.Module):
         self.relu = nn.ReLU(inplace=True)          # kept for parity; never applied (reference :191-193)
         conv_init(self.conv)
         bn_init(self.bn, 1)
+        Fn.tag_batchnorms_(self)
 
     def forward(self, x):
         cfg = (self.kernel_size, self.stride, 1, self.pad, self.bn)
@@ -179,6 +181,7 @@ class MultiScale_TemporalConv(nn.Module):
             self.residual = TemporalConv(in_channels, out_channels, kernel_size=residual_kernel_size, stride=stride)
         self._rk = residual_kernel_size
         self.apply(weights_init)
+        Fn.tag_batchnorms_(self)
 
     # ---- parameter plumbing -------------------------------------------------
     def _tensors(self):
@@ -329,6 +332,7 @@ class unit_gcn(nn.Module):
                 nn.init.constant_(m.weight, 0)
                 if m.bias is not None:
                     nn.init.constant_(m.bias, 0)
+        Fn.tag_batchnorms_(self)
 
     # ---- parameter plumbing -------------------------------------------------
     def _graph(self, device):
@@ -460,6 +464,7 @@ class Model(nn.Module):
         nn.init.normal_(self.fc.weight, 0, math.sqrt(2. / num_class))
         bn_init(self.data_bn, 1)
         self.drop_out = nn.Dropout(drop_out) if drop_out else (lambda x: x)
+        Fn.tag_batchnorms_(self)
 
     def _blocks(self, x, emit_pool=False):
         if x.dim() == 3:                                   # (N, T, V*C) form, reference :325-327

@@ -67,18 +67,28 @@ class st_gcn(nn.Module):
             self.residual = nn.Sequential(nn.Conv2d(in_channels, out_channels, kernel_size=1, stride=(stride, 1)),
                                           nn.BatchNorm2d(out_channels))
         self.relu = nn.ReLU(inplace=True)
+        Fn.tag_batchnorms_(self)
 
     def forward(self, x, A):
         x = _require_hip(x)
-        if self._dropout and self.training:
-            raise NotImplementedError('tam_gcn_amd: st_gcn dropout > 0 in training mode (the reference configs use 0)')
         if A.size(0) != self.gcn.kernel_size:
             raise AssertionError('A.size(0) must equal the spatial kernel size')
         p = [self.gcn.conv.weight, self.gcn.conv.bias, self.tcn[0].weight, self.tcn[0].bias, self.tcn[2].weight, self.tcn[2].bias,
              self.tcn[3].weight, self.tcn[3].bias]
+        if self._dropout and self.training:
+            # reference :82-88, :96-99 with an active Dropout between the second BatchNorm and the residual add: the fused node
+            # stops at bn2(conv(relu(bn1(gcn(x))))); dropout, the residual branch and the final ReLU follow as separate ops
+            z = Fn.StGcnFn.run(self, False, x, A, *p)
+            z = torch.nn.functional.dropout(z, self._dropout, True)
+            if self._rmode == 'identity':
+                z = z + x
+            elif self._rmode == 'conv':
+                r = self.residual
+                z = z + Fn.ConvBNFn.run((1, self.stride, 1, 0, r[1]), x, r[0].weight, r[0].bias, r[1].weight, r[1].bias)
+            return torch.relu(z), A
         if self._rmode == 'conv':
             p += [self.residual[0].weight, self.residual[0].bias, self.residual[1].weight, self.residual[1].bias]
-        return Fn.StGcnFn.run(self, x, A, *p), A
+        return Fn.StGcnFn.run(self, True, x, A, *p), A
 
 
 class Model(nn.Module):
@@ -96,24 +106,18 @@ class Model(nn.Module):
         kernel_size = (temporal_kernel_size, spatial_kernel_size)
         self.num_point = num_point
         self.data_bn = nn.BatchNorm1d(num_person * in_channels * num_point)
-        self.st_gcn_networks = nn.ModuleList((
-            st_gcn(in_channels, 64, kernel_size, 1, residual=False, **kwargs),
-            st_gcn(64, 64, kernel_size, 1, **kwargs),
-            st_gcn(64, 64, kernel_size, 1, **kwargs),
-            st_gcn(64, 64, kernel_size, 1, **kwargs),
-            st_gcn(64, 128, kernel_size, 2, **kwargs),
-            st_gcn(128, 128, kernel_size, 1, **kwargs),
-            st_gcn(128, 128, kernel_size, 1, **kwargs),
-            st_gcn(128, 256, kernel_size, 2, **kwargs),
-            st_gcn(256, 256, kernel_size, 1, **kwargs),
-            st_gcn(256, 256, kernel_size, 1, **kwargs),
-        ))
+        # (Cin, Cout, temporal stride) of the ten blocks, reference :140-151; the first one has no residual
+        c = 64
+        plan = [(in_channels, c, 1)] + [(c, c, 1)] * 3 + [(c, 2 * c, 2)] + [(2 * c, 2 * c, 1)] * 2 + [(2 * c, 4 * c, 2)] + [(4 * c, 4 * c, 1)] * 2
+        self.st_gcn_networks = nn.ModuleList(
+            st_gcn(ci, co, kernel_size, s, **(dict(kwargs, residual=False) if i == 0 else kwargs)) for i, (ci, co, s) in enumerate(plan))
         if edge_importance_weighting:
             self.edge_importance = nn.ParameterList([nn.Parameter(torch.ones(self.A.size())) for _ in self.st_gcn_networks])
         else:
             self.edge_importance = [1] * len(self.st_gcn_networks)
         self.fcn = nn.Conv2d(256, num_class, kernel_size=1)
         self.drop_out = nn.Dropout(dropout) if dropout else (lambda x: x)
+        Fn.tag_batchnorms_(self)
 
     def _blocks(self, x):
         if len(x.shape) == 3:
@@ -143,11 +147,8 @@ class Model(nn.Module):
 
     def get_edge_importance_per_joint(self):
         """Mean incoming + outgoing edge weight per joint over all layers, normalised to max 1 (reference :224-252)."""
-        V = self.A.size(1)
-        joint_scores = np.zeros(V)
-        for importance in self.edge_importance:
-            imp = importance.detach().cpu().numpy()
-            for k in range(imp.shape[0]):
-                joint_scores += imp[k].sum(axis=0)
-                joint_scores += imp[k].sum(axis=1)
-        return joint_scores / joint_scores.max()
+        if not isinstance(self.edge_importance, nn.ParameterList):
+            raise AttributeError('edge_importance_weighting=False: there are no edge weights to summarise')
+        imp = torch.stack([p.detach() for p in self.edge_importance]).double().cpu()      # (layers, K, V, V)
+        scores = (imp.sum((0, 1, 2)) + imp.sum((0, 1, 3))).numpy()                        # column sums + row sums per joint
+        return scores / scores.max()

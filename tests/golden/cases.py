@@ -47,6 +47,12 @@ MODULE_CASES = [
     ('gcn_128_256_v64',     'unit_gcn',     dict(in_channels=128, out_channels=256),                           (1, 128, 5, 64), 12),
     ('unit_64_64_v64',      'TCN_GCN_unit', dict(in_channels=64, out_channels=64, stride=1, residual=True),    (2, 64, 9, 64),  16),
     ('unit_256_256_v64',    'TCN_GCN_unit', dict(in_channels=256, out_channels=256, stride=1, residual=True),  (1, 256, 12, 64), 16),
+    # round 3: V = 64 beyond ONE 32-frame chunk of the streaming kernels (ctrgc_agg_fwd/bwd, ctrgc_de_acc_mfma) and of the
+    # joint-sliced k x 1 convolutions with their 8 halo frames: three chunks with a ragged tail (80 = 32 + 32 + 16,
+    # 72 = 32 + 32 + 8); config 4 itself is T = 512 (tests/test_gpu_configs.py holds its full-size properties)
+    ('ctrgc_64_64_v64_t80',   'CTRGC',        dict(in_channels=64, out_channels=64),                            (1, 64, 80, 64),  11),
+    ('unit_256_256_v64_t72',  'TCN_GCN_unit', dict(in_channels=256, out_channels=256, stride=1, residual=True), (1, 256, 72, 64), 16),
+    ('unit_64_128_s2_v64_t70', 'TCN_GCN_unit', dict(in_channels=64, out_channels=128, stride=2, residual=True), (1, 64, 70, 64),  16),
 ]
 
 NEEDS_A = ('unit_gcn', 'TCN_GCN_unit')      # ctor takes the (3,V,V) graph array

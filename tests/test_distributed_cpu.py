@@ -144,7 +144,8 @@ def _model_worker(rank, world, port, out):
     m = Model(**_MARGS)
     fill_state_(m.state_dict(), seed=50 + rank)              # replicas start different on purpose
     arena = ParamArena(m)
-    broadcast_state(m, src=0)
+    broadcast_state(m, src=0, arena=arena)                    # ONE broadcast of the arena + one per dtype of packed buffers
+    out[f's{rank}'] = {k: v.clone() for k, v in m.state_dict().items()}
     bucket = arena.grad_bucket()
     opt = SGDNesterov(arena.params, lr=0.01, momentum=0.9, weight_decay=1e-4, arena=arena, bucket=bucket)
     n_global = 8
@@ -175,6 +176,12 @@ def test_two_rank_real_model_arena_uneven_shards():
     mp.spawn(_model_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert torch.equal(out[0], out[1])                          # replicas identical after the step
     assert torch.equal(out['g0'], out['g1'])
+    ref = Model(**_MARGS)                                       # the packed broadcast delivered rank 0's whole state: parameters,
+    fill_state_(ref.state_dict(), seed=50)                      # running statistics, num_batches_tracked counters
+    for r in (0, 1):
+        st = out[f's{r}']
+        assert list(st.keys()) == list(ref.state_dict().keys())
+        assert all(torch.equal(st[k], v) and st[k].dtype == v.dtype for k, v in ref.state_dict().items())
     # single-process emulation: per-shard gradients (per-replica BatchNorm statistics, as nn.DataParallel computes them)
     # weighted by shard size = the gradient of the mean loss over the 8 clips
     m = Model(**_MARGS)
@@ -210,6 +217,13 @@ def test_bench_self_launches_two_ranks_rehearsal():
     js = json.loads(lines[0])
     assert js['n_gpus'] == 2 and js['steps'] == 3 and js['config']['rehearsal'] is True and js['value'] is None
     assert js['config']['global_batch'] == 512 and js['scaling'] == 'weak'
+    assert js['cpu_baseline'] is None and js['cpu_baseline_absent_because']
+    # configs[2]: four models, one arena / bucket, one all-reduce -- the same control flow
+    r4 = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--config', '4stream'],
+                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r4.returncode == 0, r4.stderr.decode()[-2000:]
+    js4 = json.loads([ln for ln in r4.stdout.decode().splitlines() if ln.startswith('{')][0])
+    assert js4['n_gpus'] == 2 and js4['config']['streams'] == 4 and js4['config']['global_batch'] == 256 and js4['value'] is None
     # a launcher environment that disagrees with --gpus is an error, not silently ignored
     env2 = dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
     r2 = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'], env=env2, stdout=subprocess.PIPE,

@@ -1,0 +1,350 @@
+"""-m gpu: the BASELINE.json configurations as WHOLE paths (each kernel family is pinned elsewhere; these tests
+chain them the way the configurations do).
+
+config 0  feeder -> (1, 3, 52, 20, 1) -> Model.forward -> (1, 10)            (reference feeder/feeder_nucla_gcn.py:85-130,154
+                                                                              -> models/ctrgcn.py:324-348)
+config 2  four Models on joint / bone / motion / bone-motion clips derived on the GPU, ONE parameter arena, ONE gradient
+          bucket, one step: losses and the packed bucket against the oracle on the four derived inputs, flat SGD state
+          against four per-model torch.optim.SGD                             (feeder_nucla_gcn.py:119-127, the harness recipe
+                                                                              processor/recognition_rgb.py:19-28)
+          + the same four models on four HIP streams, eager and captured into a HIP graph (bench.py --config 4stream)
+config 4  TCN_GCN_unit(256, 256) on (clips, 256, 512, 64): size-independent properties at 32 clips x 512 frames
+          (module parity at V = 64 over several frame chunks: tests/golden cases *_v64_t*)
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from cases import MODEL_CASES, MODEL_PARAM_SEED                                  # noqa: E402
+from params import fill_state_, make_input, make_labels                          # noqa: E402
+from oracle import ctrgcn_oracle as O                                            # noqa: E402
+from tam_gcn_amd import ops                                                      # noqa: E402
+from tam_gcn_amd.models import ctrgcn as M                                       # noqa: E402
+from tam_gcn_amd.feeder.feeder_nucla_gcn import Feeder, BONE_PARENT              # noqa: E402
+
+UCLA = MODEL_CASES[0][1]
+STREAMS = ('joint', 'bone', 'motion', 'bone_motion')
+FEEDER_GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'feeder.npz'))
+
+
+def _rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# config 0
+# ---------------------------------------------------------------------------------------------------------------------
+def test_config0_feeder_sample_through_model(tmp_path, golden_models):
+    """One clip file on disk -> Feeder(...)[0] (val path: the reference's own Feeder produced the expected sample,
+    tests/golden/feeder.npz) -> batch of one -> Model in eval mode -> (1, 10) logits against the oracle fed the
+    FIXTURE's sample (so a feeder error and a model error cannot cancel)."""
+    i = 7
+    name = str(FEEDER_GOLD[f'val/{i}/name'])
+    os.makedirs(tmp_path / name)
+    with open(tmp_path / name / (name + '.json'), 'w') as f:
+        json.dump({'skeletons': FEEDER_GOLD[f'val/{i}/raw'].tolist()}, f)
+    fd = Feeder(str(tmp_path), 'val', data_dict=[{'file_name': name, 'label': int(FEEDER_GOLD[f'val/{i}/label']) + 1}])
+    data, rgb, label, index = fd[0]
+    want = FEEDER_GOLD[f'val/{i}/data']
+    assert data.shape == (3, 52, 20, 1) and data.dtype == np.float32 and np.array_equal(data, want)
+    assert label == int(FEEDER_GOLD[f'val/{i}/label']) and index == 0
+    dev = torch.device('cuda:0')
+    m = M.Model(**UCLA)
+    fill_state_(m.state_dict(), seed=MODEL_PARAM_SEED)
+    sd0 = m.state_dict()
+    with torch.no_grad():                                  # realistic running statistics (the ucla_t52 fixture's)
+        for k in sd0:
+            if 'running_' in k:
+                sd0[k].copy_(torch.from_numpy(golden_models[f'ucla_t52/evalbuf/{k}']))
+    sd = O.clone_state(m.state_dict())
+    ref = O.model_forward(torch.from_numpy(want)[None], sd, 20, training=False)
+    m = m.to(dev).eval()
+    x = torch.from_numpy(data)[None].to(dev)               # what a DataLoader with batch_size 1 hands the model
+    with torch.no_grad():
+        logits = m(x)
+        feat, _ = m.extract_feature(x)
+    assert tuple(logits.shape) == (1, 10) and tuple(feat.shape) == (1, 256, 13, 20, 1)
+    assert float((logits.cpu() - ref).abs().max()) <= 1e-3
+    assert int(logits.argmax(1)) == int(ref.argmax(1))
+    # the batch form the data-parallel step uses gives the same clip
+    xb, lab, _ = fd.batch([0])
+    with torch.no_grad():
+        assert torch.equal(m(xb), logits) and lab.tolist() == [label]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# config 2
+# ---------------------------------------------------------------------------------------------------------------------
+def _derive_cpu(x, name):
+    """The four streams as the reference's feeder / upstream CTR-GCN define them (feeder_nucla_gcn.py:119-127)."""
+    if name == 'joint':
+        return x
+    pl = torch.tensor(BONE_PARENT, dtype=torch.long)
+    bone = x - x[:, :, :, pl, :]
+    if name == 'bone':
+        return bone
+    src = x if name == 'motion' else bone
+    out = torch.zeros_like(src)
+    out[:, :, :-1] = src[:, :, 1:] - src[:, :, :-1]
+    return out
+
+
+def _four_models(dev):
+    models = torch.nn.ModuleList()
+    for i in range(4):
+        m = M.Model(**UCLA)
+        fill_state_(m.state_dict(), seed=MODEL_PARAM_SEED + i)
+        models.append(m)
+    return models.to(dev).train()
+
+
+def test_config2_four_streams_one_arena_one_bucket():
+    from tam_gcn_amd.distributed import ParamArena, SGDNesterov
+    from tam_gcn_amd.functional import CrossEntropyLoss
+    dev = torch.device('cuda:0')
+    B, T = 6, 64
+    x = make_input((B, 3, T, 20, 1), seed=31)
+    lab = make_labels(B, 10, seed=32)
+    # --- oracle: four independent models on the four derived inputs (CPU, fp64 = what every fp32 evaluation approximates)
+    ref_loss, ref_grads, ref_logits = [], [], []
+    cpu_models = _four_models(torch.device('cpu'))
+    for name, m in zip(STREAMS, cpu_models):
+        sd = {k: (v.detach().clone().double() if v.is_floating_point() else v.clone()) for k, v in m.state_dict().items()}
+        for k, _ in m.named_parameters():
+            sd[k].requires_grad_(True)
+        lo = O.model_forward(_derive_cpu(x, name).double(), sd, 20, training=True)
+        loss = torch.nn.functional.cross_entropy(lo, lab)
+        loss.backward()
+        ref_loss.append(float(loss))
+        ref_logits.append(lo.detach())
+        ref_grads.append({k: sd[k].grad for k, _ in m.named_parameters()})
+    # --- HIP: the step of bench.py --config 4stream
+    models = _four_models(dev)
+    arena = ParamArena(models)
+    bucket = arena.grad_bucket()
+    assert arena.total * 4 > 4 * 6.7e6 and arena.intact()          # one 27 MB buffer
+    opt = SGDNesterov(arena.params, lr=0.01, momentum=0.9, weight_decay=1e-4, arena=arena, bucket=bucket)
+    ce = CrossEntropyLoss()
+    xg, lg = x.to(dev), lab.to(dev)
+    parent = torch.tensor(BONE_PARENT, dtype=torch.int32, device=dev)
+    bucket.zero()
+    losses, logits = [], []
+    total = None
+    for name, m in zip(STREAMS, models):
+        xs = xg if name == 'joint' else ops.stream_derive(xg, parent, name)
+        assert torch.equal(xs.cpu(), _derive_cpu(x, name))           # the derivation kernel is exact
+        out = m(xs)
+        loss = ce(out, lg)
+        logits.append(out.detach())
+        losses.append(loss.detach())
+        total = loss if total is None else total + loss
+    total.backward()
+    flat = bucket.pack()
+    torch.cuda.synchronize()
+    for i, name in enumerate(STREAMS):
+        assert float((logits[i].cpu().double() - ref_logits[i]).abs().max()) <= 1e-3, name
+        assert torch.equal(logits[i].argmax(1).cpu(), ref_logits[i].argmax(1)), name
+        assert abs(float(losses[i]) - ref_loss[i]) <= 1e-3, name
+    # the packed bucket: every parameter's slot holds that parameter's gradient (layout), and each model's segment
+    # matches the oracle in the flip-robust metrics of tests/test_gpu_model.py (6 clips: ReLU masks differ between any
+    # two fp32 evaluations), fc gradients (forward features only) tightly
+    pos = {id(p): (o, p.numel()) for p, o in zip(arena.params, arena.offsets)}
+    flat_c = flat.detach().cpu().double()
+    for i, (name, m) in enumerate(zip(STREAMS, models)):
+        got, ref = [], []
+        for k, p in m.named_parameters():
+            o, n = pos[id(p)]
+            assert p.grad.data_ptr() == flat.data_ptr() + 4 * o                 # .grad is the bucket's view
+            got.append(flat_c[o:o + n])
+            ref.append(ref_grads[i][k].reshape(-1))
+        g, r = torch.cat(got), torch.cat(ref)
+        l2 = float((g - r).norm() / r.norm())
+        cos = float((g * r).sum() / (g.norm() * r.norm()))
+        assert l2 <= 5e-2 and cos >= 0.999, (name, l2, cos)
+        assert _rel(m.fc.weight.grad, ref_grads[i]['fc.weight']) <= 1e-3, name
+    # padding between aligned runs stays zero (it is all-reduced and fed to the flat optimiser with the rest)
+    mask = torch.ones(arena.total, dtype=torch.bool)
+    for p, o in zip(arena.params, arena.offsets):
+        mask[o:o + p.numel()] = False
+    assert float(flat.cpu()[mask].abs().max() if mask.any() else 0.0) == 0.0
+    # --- flat SGD on the arena == four torch.optim.SGD on four separate models given the same gradients
+    twins = _four_models(dev)
+    opts = [torch.optim.SGD(t.parameters(), lr=0.01, momentum=0.9, nesterov=True, weight_decay=1e-4) for t in twins]
+    for step in range(2):                                            # two steps: the momentum buffers matter in the second
+        if step:
+            bucket.zero()
+            tot = None
+            for name, m in zip(STREAMS, models):
+                xs = xg if name == 'joint' else ops.stream_derive(xg, parent, name)
+                l_ = ce(m(xs), lg)
+                tot = l_ if tot is None else tot + l_
+            tot.backward()
+            bucket.pack()
+        for name, t, o_ in zip(STREAMS, twins, opts):
+            o_.zero_grad()
+            xs = xg if name == 'joint' else ops.stream_derive(xg, parent, name)
+            ce(t(xs), lg).backward()
+            o_.step()
+        opt.step()
+    torch.cuda.synchronize()
+    for m, t in zip(models, twins):
+        sa, sb = m.state_dict(), t.state_dict()
+        assert list(sa.keys()) == list(sb.keys()) and len(sa) == 892
+        for k in sa:
+            if sa[k].is_floating_point():
+                assert _rel(sa[k], sb[k]) <= 2e-5, k
+            else:
+                assert torch.equal(sa[k], sb[k]), k
+
+
+def _two_model_step(models, xs, lab, streams):
+    """fwd + CE + bwd of every model, model i on streams[i] (None: the current stream); returns losses."""
+    from tam_gcn_amd.functional import CrossEntropyLoss
+    ce = CrossEntropyLoss()
+    cur = torch.cuda.current_stream()
+    for m in models:
+        for p in m.parameters():
+            p.grad = None
+    losses = []
+    for m, x, st in zip(models, xs, streams):
+        if st is None:
+            losses.append(ce(m(x), lab))
+            continue
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            losses.append(ce(m(x), lab))
+    for st in streams:
+        if st is not None:
+            cur.wait_stream(st)
+    total = losses[0]
+    for l_ in losses[1:]:
+        total = total + l_
+    total.backward()                                        # autograd replays every node on its forward's stream and joins
+    return [l_.detach() for l_ in losses]
+
+
+def test_models_on_separate_streams_eager_and_captured():
+    """Two (then four) Models, each on its own HIP stream -- forward and, through autograd, backward -- as
+    bench.py --config 4stream runs them: bit-identical to the same step on ONE stream, eagerly and replayed from a HIP
+    graph.  Every main stream owns its side streams (functional._side_streams): blocks of the caching allocator never
+    move between two models' streams."""
+    from tam_gcn_amd import functional as Fn
+    dev = torch.device('cuda:0')
+    nm = 4
+    models = _four_models(dev)
+    x = make_input((4, 3, 32, 20, 1), seed=41).to(dev)
+    lab = make_labels(4, 10, seed=42).to(dev)
+    parent = torch.tensor(BONE_PARENT, dtype=torch.int32, device=dev)
+    xs = [x if n == 'joint' else ops.stream_derive(x, parent, n) for n in STREAMS]
+    state0 = [{k: v.clone() for k, v in m.state_dict().items()} for m in models]
+
+    def reset():
+        for m, s in zip(models, state0):
+            m.load_state_dict(s)
+
+    def grads():
+        return [[p.grad.clone() for p in m.parameters()] for m in models]
+
+    ref_loss = _two_model_step(models, xs, lab, [None] * nm)
+    torch.cuda.synchronize()
+    ref_grads = grads()
+    ref_state = [{k: v.clone() for k, v in m.state_dict().items()} for m in models]
+    # eager, one stream per model
+    reset()
+    sts = [torch.cuda.Stream(dev) for _ in range(nm)]
+    loss = _two_model_step(models, xs, lab, sts)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(loss, ref_loss))
+    for ga, gb in zip(grads(), ref_grads):
+        assert all(torch.equal(a, b) for a, b in zip(ga, gb))
+    for m, s in zip(models, ref_state):                     # running statistics written through raw pointers
+        assert all(torch.equal(v, s[k]) for k, v in m.state_dict().items())
+    keys = [k for k in Fn._SIDE if k[0] == dev.index]
+    assert {s.cuda_stream for s in sts} <= {k[1] for k in keys}    # each model stream got its own side pool (empty if torch's
+    handles = [s.cuda_stream for k in keys for s in Fn._SIDE[k]]   # 32-stream pool had wrapped around: then it runs in order)
+    assert len(handles) == len(set(handles))                       # no side stream serves two main streams
+    # captured: warm-up on a side stream, capture, replay twice
+    reset()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        closs = _two_model_step(models, xs, lab, sts)
+    cgrads = [[p.grad for p in m.parameters()] for m in models]
+    for _ in range(2):
+        reset()
+        g.replay()
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(closs, ref_loss))
+        for ga, gb in zip(cgrads, ref_grads):
+            assert all(torch.equal(a, b) for a, b in zip(ga, gb))
+        for m, s in zip(models, ref_state):
+            assert all(torch.equal(v, s[k]) for k, v in m.state_dict().items())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# config 4
+# ---------------------------------------------------------------------------------------------------------------------
+def test_config4_full_size_properties():
+    """BASELINE configs[4] at its frame count: ONE TCN_GCN_unit(256, 256) on (32, 256, 512, 64) -- 16 frame chunks of the
+    streaming aggregation kernels, the joint-sliced k x 1 convolutions, 1.07 GB per activation.  No oracle run is affordable
+    here; the domain's size-independent properties: (1) eval mode: a clip's output does not depend on the batch it sits in
+    (32-clip launch vs 2-clip launch); (2) train mode: permuting the batch permutes the output and leaves every parameter
+    gradient unchanged; (3) temporal locality: the block's receptive field is +-4 frames, so the eval output of frames
+    [0, 200) of a clip is unchanged by what happens in frames >= 204 -- except through CTRGC's mean over T, which is held
+    fixed by making the perturbation zero-mean over T per (channel, joint)."""
+    from helpers import A_BY_V
+    dev = torch.device('cuda:0')
+    C, T, V, NB = 256, 512, 64, 32
+    torch.manual_seed(0)
+    blk = M.TCN_GCN_unit(C, C, A_BY_V[V])
+    fill_state_(blk.state_dict(), seed=77)
+    blk = blk.to(dev)
+    g = torch.Generator().manual_seed(13)
+    x = (torch.rand(NB, C, T, V, generator=g) * 2 - 1).to(dev)
+    blk.train()
+    for mod in blk.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.momentum = 1.0                               # running statistics := this batch's
+    with torch.no_grad():
+        blk(x)
+    blk.eval()
+    with torch.no_grad():
+        full = blk(x)
+        sub = blk(x[10:12].contiguous())
+        assert torch.isfinite(full).all()
+        scale = float(full.abs().max())
+        assert float((full[10:12] - sub).abs().max()) <= 1e-4 * scale
+        # (3) a zero-mean-over-T perturbation confined to frames >= 204
+        x2 = x[10:12].clone()
+        d = (torch.rand(2, C, 8, V, generator=g) * 2 - 1).to(dev)
+        x2[:, :, 300:308] += d
+        x2[:, :, 400:408] -= d
+        y2 = blk(x2)
+        assert float((y2[:, :, :200] - sub[:, :, :200]).abs().max()) <= 1e-4 * scale
+        assert float((y2[:, :, 300:308] - sub[:, :, 300:308]).abs().max()) > 1e-2 * scale
+    del full, y2
+    blk.train()
+    cot = (torch.rand(NB, C, T, V, generator=g) * 2 - 1).to(dev)
+    perm = torch.randperm(NB, generator=g).to(dev)
+    xr = x.clone().requires_grad_(True)
+    out = blk(xr)
+    out.backward(cot)
+    g1 = {k: p.grad.clone() for k, p in blk.named_parameters()}
+    dx1 = xr.grad
+    for p in blk.parameters():
+        p.grad = None
+    xp = x[perm].contiguous().requires_grad_(True)
+    outp = blk(xp)
+    outp.backward(cot[perm].contiguous())
+    torch.cuda.synchronize()
+    assert float((outp.detach() - out.detach()[perm]).abs().max()) <= 2e-4 * float(out.detach().abs().max())
+    assert float((xp.grad - dx1[perm]).abs().max()) <= 2e-3 * float(dx1.abs().max())
+    gmax = max(float(v.norm()) for v in g1.values())
+    for k, p in blk.named_parameters():                     # (biases in front of a train-mode BatchNorm: exact-zero gradients,
+        n1 = float(g1[k].norm())                            # rounding noise only -- hence the floor)
+        assert float((g1[k] - p.grad).norm()) <= 5e-3 * n1 + 1e-4 * gmax, k

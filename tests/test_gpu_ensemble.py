@@ -66,3 +66,15 @@ def test_first_maximum_wins_ties_and_four_streams():
     assert np.allclose(fused.cpu().numpy(), (s * np.array([1, 2, 1, 1], np.float32)[:, None, None]).sum(0))
     with pytest.raises(ValueError):
         E.fuse(list(s), [1.0])
+
+
+def test_out_of_range_label_is_refused():
+    """The kernel leaves a label outside [0, K) out of every class row while the scripts' accuracy divides by
+    len(labels): the Python layer refuses such input instead of returning a different denominator."""
+    s = _scores(8, 5, 9)
+    for bad in (5, -1):
+        lab = np.array([0, 1, 2, 3, 4, 0, 1, bad])
+        with pytest.raises(ValueError, match='label outside'):
+            E.fuse([s], [1.0], labels=lab)
+        with pytest.raises(ValueError, match='label outside'):
+            E.compute_accuracy(s, lab)

@@ -398,6 +398,28 @@ def test_cross_entropy_against_torch():
         (ref * 1.7).backward()
         assert abs(float(loss) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
         assert (logits.grad.double() - ref_l.grad).abs().max() <= 2e-7
+    # nn.CrossEntropyLoss's default ignore_index = -100: skipped rows, mean over the kept ones
+    N, K = 37, 10
+    logits = (torch.randn(N, K, generator=g) * 3).to(dev).requires_grad_(True)
+    lab = torch.randint(0, K, (N,), generator=g)
+    lab[::5] = -100
+    lab = lab.to(dev)
+    loss = CrossEntropyLoss()(logits, lab)
+    loss.backward()
+    ref_l = logits.detach().double().clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(ref_l, lab)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+    assert (logits.grad.double() - ref_l.grad).abs().max() <= 2e-7 and float(logits.grad[::5].abs().max()) == 0.0
+    assert torch.isnan(CrossEntropyLoss()(logits.detach(), torch.full((N,), -100, device=dev)))       # nothing kept: NaN, as torch
+    # a label outside [0, K) (torch: device assert): NaN loss, that row's gradient zero, no out-of-bounds read
+    for badv in (K, -1, 10 ** 12):
+        lab2 = lab.clone()
+        lab2[3] = badv
+        lg = logits.detach().clone().requires_grad_(True)
+        loss = CrossEntropyLoss()(lg, lab2)
+        loss.backward()
+        assert torch.isnan(loss) and float(lg.grad[3].abs().max()) == 0.0
 
 
 def test_three_term_split_forward_gemm_matches_exact_kernels():

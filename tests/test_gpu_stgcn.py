@@ -104,3 +104,49 @@ def test_model_parity(case):
     assert abs(digest(o)[1] - GOLD[f'{tag}/out_digest'][1]) <= 1e-3 * abs(GOLD[f'{tag}/out_digest'][1])
     js = m.get_edge_importance_per_joint()
     assert js.shape == (20,) and abs(js.max() - 1.0) < 1e-12
+
+
+@pytest.mark.parametrize('case', [STGCN_BLOCK_CASES[1], STGCN_BLOCK_CASES[2], STGCN_BLOCK_CASES[0]], ids=lambda c: c[0])
+def test_block_with_active_dropout(case, monkeypatch):
+    """st_gcn(dropout > 0) in training mode (reference models/stgcn.py:82-88, :96-99: Dropout sits between the second
+    BatchNorm and the residual add).  The fused node then stops at the BatchNorm and the tail runs as separate ops: with the
+    dropout mask forced to identity that composition must reproduce the fused block -- output and every gradient -- and with
+    the real mask it must zero ~p of the pre-residual values and scale the rest by 1 / (1 - p)."""
+    tag, kw, shape, xseed = case
+    dev = torch.device('cuda:0')
+    args = (kw['in_channels'], kw['out_channels'], (9, 3), kw.get('stride', 1))
+
+    def run(dropout, identity_mask):
+        blk = M.st_gcn(*args, dropout=dropout, residual=kw.get('residual', True))
+        fill_state_(blk.state_dict(), seed=tag_seed(tag))
+        blk = blk.to(dev).train()
+        x = make_input(shape, xseed).to(dev).requires_grad_(True)
+        imp = (1 + 0.1 * make_input((3, 20, 20), seed=31)).to(dev).requires_grad_(True)
+        if identity_mask:
+            monkeypatch.setattr(torch.nn.functional, 'dropout', lambda z, p, training: z * 1.0)
+        y, _ = blk(x, A.to(dev) * imp)
+        monkeypatch.undo()
+        cot = make_input(tuple(y.shape), seed=COT_SEED).to(dev)
+        (y * cot).sum().backward()
+        torch.cuda.synchronize()
+        return y.detach(), x.grad, imp.grad, {k: p.grad for k, p in blk.named_parameters()}, {k: b.clone() for k, b in blk.named_buffers()}
+
+    y0, dx0, di0, g0, b0 = run(0, False)                       # the fused block
+    y1, dx1, di1, g1, b1 = run(0.5, True)                      # unfused tail, mask = identity
+    _cmp('y', y1, y0.cpu(), 1e-6); _cmp('dx', dx1, dx0.cpu(), 2e-5); _cmp('d importance', di1, di0.cpu(), 2e-5)
+    for k in g0:
+        _cmp(k, g1[k], g0[k].cpu(), 2e-5, 1e-6)
+    for k in b0:
+        _cmp(k, b1[k].float(), b0[k].float().cpu(), 1e-6)
+    torch.manual_seed(3)
+    y2, dx2, _, g2, _ = run(0.5, False)                        # the real mask
+    assert torch.isfinite(y2).all() and torch.isfinite(dx2).all() and all(torch.isfinite(v).all() for v in g2.values())
+    assert float((y2 - y0).abs().max()) > 1e-2 * float(y0.abs().max())
+    blk = M.st_gcn(*args, dropout=0.5, residual=kw.get('residual', True))     # eval mode: dropout is the identity, fused path
+    fill_state_(blk.state_dict(), seed=tag_seed(tag))
+    ref = M.st_gcn(*args, dropout=0, residual=kw.get('residual', True))
+    ref.load_state_dict(blk.state_dict())
+    blk, ref = blk.to(dev).eval(), ref.to(dev).eval()
+    with torch.no_grad():
+        xe = make_input(shape, xseed).to(dev)
+        assert torch.equal(blk(xe, A.to(dev))[0], ref(xe, A.to(dev))[0])

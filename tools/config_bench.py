@@ -45,9 +45,14 @@ def kernel_table(step):
     rows = []
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1]['ms']):
         sec = a['ms'] * 1e-3
+        # the split GEMMs spend three bf16 MFMAs per fp32 product: their matrix roof is the dense bf16 peak / 3, not the
+        # fp32-input MFMA peak (against which they would read > 1)
+        split = 'split_kernel<2' in k or ', split,' in k
+        peak = B.BF16_MFMA_PEAK / 3.0 if split else B.F32_MFMA_PEAK
         rows.append(dict(kernel=k, launches=a['calls'], ms=round(a['ms'], 3),
                          hbm_frac=round(a['bytes'] / sec / B.HBM_PEAK, 4) if a['bytes'] else None,
-                         mfma_f32_frac=round(a['flops'] / sec / B.F32_MFMA_PEAK, 4) if a['flops'] else None))
+                         mfma_frac=round(a['flops'] / sec / peak, 4) if a['flops'] else None,
+                         mfma_peak_tflops=round(peak / 1e12, 1)))
     return rows, B.ctrgc_layer_table(layers)
 
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU-box script: the round's profile artefacts.  usage: bash tools/profile_round.sh <tag>   (e.g. r01c)
+# GPU-box script: the round's profile artefacts.  usage: bash tools/profile_round.sh <tag> [commit]   (e.g. r03a $(git rev-parse --short HEAD))
 #   gpurun_out/<tag>_bench_kernel_stats.csv    rocprofv3 --kernel-trace --stats of `python3 bench.py`
 #   gpurun_out/<tag>_bench_under_rocprof.json  the bench line of that run
 #   gpurun_out/<tag>_pmc_traffic.txt, traffic.json   FETCH_SIZE / WRITE_SIZE passes (separate runs) -> HBM bytes per launch
@@ -7,6 +7,7 @@
 # Copy what should be judged into profiles/.
 set -o pipefail
 TAG=${1:-r01}
+COMMIT=${2:-unknown}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out
 rm -rf $O/prof_stats $O/prof_fetch $O/prof_write $O/prof_serial
@@ -16,7 +17,7 @@ cp $(ls $O/prof_stats/*/*kernel_stats.csv | head -1) $O/${TAG}_bench_kernel_stat
 echo "stats done"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pf.log 2>&1 || exit 3
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pw.log 2>&1 || exit 4
-python tools/pmc_traffic.py $O/prof_fetch $O/prof_write $O/traffic.json > $O/${TAG}_pmc_traffic.txt || exit 5
+python tools/pmc_traffic.py $O/prof_fetch $O/prof_write $O/traffic.json "$TAG @ commit $COMMIT" > $O/${TAG}_pmc_traffic.txt || exit 5
 echo "pmc done"
 TAMGCN_SIDE_STREAMS=0 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/prof_serial -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline > $O/ps.log 2>&1 || exit 6
 python tools/step_breakdown.py $(ls $O/prof_serial/*/*kernel_trace.csv | head -1) auto 60 > $O/${TAG}_step_breakdown.txt
