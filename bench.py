@@ -75,7 +75,7 @@ class _Probe:
         if not name.startswith('tamgcn_') or name in ('tamgcn_last_error', 'tamgcn_last_kernel', 'tamgcn_version', 'tamgcn_conv_nparts',
                                                      'tamgcn_ew_nparts', 'tamgcn_ctrgc_lds_bytes', 'tamgcn_get_split_mode',
                                                      'tamgcn_set_split_mode', 'tamgcn_wgrad_max_split', 'tamgcn_ctrgc_tiled_supported',
-                                                     'tamgcn_ctrgc_tiled_chunks', 'tamgcn_set_split3_fwd', 'tamgcn_set_rows128'):
+                                                     'tamgcn_ctrgc_tiled_chunks'):
             return fn
 
         def wrapped(*args):
@@ -135,10 +135,6 @@ def _algorithmic(name, args):
     if name == 'tamgcn_ctrgc_bwd_dx3':
         b = d.N * d.T * d.V * (2 * d.Cout + d.S * d.Cout)
         f = d.N * d.S * (2.0 * d.R * d.Cout * d.V * d.V + 2.0 * d.Cout * d.T * d.V * d.V)
-        return (4.0 * b, f)
-    if name == 'tamgcn_ctrgc_bwd_de':
-        b = d.N * d.T * d.V * (d.Cin + 2 * d.Cout)
-        f = d.N * d.S * (2.0 * d.Cin * d.Cout * d.T * d.V + 2.0 * d.Cout * d.T * d.V * d.V + 4.0 * d.R * d.Cout * d.V * d.V)
         return (4.0 * b, f)
     return (0.0, 0.0)
 
@@ -401,7 +397,7 @@ def main():
             bucket.pack()
             loss_buf.fill_(float(rank))
     else:
-        from tam_gcn_amd import ops as _ops
+        from tam_gcn_amd import ops as _ops, functional as _Fm
         from tam_gcn_amd.functional import CrossEntropyLoss
         ce = CrossEntropyLoss()                             # the harness's nn.CrossEntropyLoss() as two HIP launches (row f1)
 
@@ -417,7 +413,7 @@ def main():
                 ctx = contextlib.nullcontext()
                 if fork:                                  # the four models are independent until the bucket: one HIP stream each.
                     model_streams[i].wait_stream(cur)     # Autograd replays every node on the stream of its forward and joins
-                    ctx = torch.cuda.stream(model_streams[i])    # the leaf streams into `cur` when backward() returns.
+                    ctx = _Fm.model_stream(model_streams[i])     # the leaf streams into `cur` when backward() returns.
                 with ctx:
                     xs = x if name == 'joint' else _ops.stream_derive(x, parent, name)
                     losses.append(ce(m(xs), lab))
@@ -558,8 +554,7 @@ def main():
             'scaling': 'weak', 'vs_baseline': None,
             'dtype': {'0': 'f32 (exact fp32-input MFMA in every GEMM, TAMGCN_SPLIT_BF16=0)',
                       '1': 'f32 (fwd GEMMs exact fp32-input MFMA; bwd weight-gradient and C>=128 data-gradient GEMMs 2-term '
-                           'bf16 split = 3 bf16 MFMAs, ~4.5e-6 rel. error, TAMGCN_SPLIT_BF16=1)',
-                      '2': 'f32 (as mode 1, and the forward x3 GEMM also 2-term bf16 split, TAMGCN_SPLIT_BF16=2)'}.get(split, split),
+                           'bf16 split = 3 bf16 MFMAs, ~4.5e-6 rel. error, TAMGCN_SPLIT_BF16=1)'}.get(split, split),
             'data': 'synthetic',
             'config': {'workload': (f'N-UCLA 4-stream (joint/bone/motion/bone-motion derived on GPU), 4 x models.ctrgcn.Model, '
                                     f'{B} clips/GPU/stream x (3,64,20,1), ONE {arena.total * 4 / 1e6:.1f} MB gradient bucket' if four else

@@ -60,22 +60,13 @@ const char* tamgcn_last_kernel(void);
 /* GEMM arithmetic policy (process-wide; initial value from the environment variable TAMGCN_SPLIT_BF16, default 1):
  *   0  exact fp32-input MFMA (v_mfma_f32_16x16x4_f32) in every GEMM;
  *   1  as 0 in the forward; weight-gradient GEMMs and the data-gradient GEMMs into >= 128 channels run as a 2-term
- *      bf16 split (three v_mfma_f32_16x16x32_bf16, ~4.5e-6 relative error): their results never feed an activation;
- *   2  as 1, and the forward x3 GEMM of the fused CTRGC kernel also as a 2-term split (gradient parity relaxed).
+ *      bf16 split (three v_mfma_f32_16x16x32_bf16, ~4.5e-6 relative error): their results never feed an activation.
  * Takes effect for launches issued after the call; not a stream operation. */
 int         tamgcn_get_split_mode(void);
 int         tamgcn_set_split_mode(int mode);
-/* Opt-in (initial value from TAMGCN_SPLIT3_FWD, default 0): with split mode >= 1 the FORWARD 1x1 convolutions into >= 128
- * channels and the fused CTRGC forward's x3 GEMM (V = 20, Cin % 32 == 0) run as a three-term bf16 split (six v_mfma_f32_16x16x32_bf16 per K = 32 step: hh, hm, mh, hl, lh, mm), which
- * reproduces the fp32 product to ~1.2e-7 relative (outputs within 1e-6 of the exact kernels, tools/split3_check.py). */
-int         tamgcn_set_split3_fwd(int on);
-/* Opt-in (initial value from TAMGCN_ROWS128, default 0): forward 1x1 convolutions into >= 128 channels whose operand
- * prologue is linear run on a 128-row tile of the LDS-DMA GEMM with the exact fp32-input MFMA (half the activation traffic
- * per flop of the 64-row kernel, but one workgroup per CU on a two-stage ring: measured slower, NTU step 186 vs 177 ms).
- * Tests compare the two. */
-int         tamgcn_set_rows128(int on);
-/* bytes of LDS the CTRGC kernels need for (S subsets, V joints, R rel-channels): the fused LDS-resident family for
- * V in {20, 25}, the tiled large-skeleton family (tamgcn_ctrgc_tiled_*) for V in {32, 64};
+
+/* bytes of LDS the CTRGC kernels need for (S subsets, V joints, R rel-channels): the fused LDS-resident workgroup for
+ * V = 20, the streaming family (tamgcn_ctrgc_tiled_*) for V in {25, 32, 64};
  * <0 if the shape is unsupported.  Lets the host fail early and loudly. */
 int         tamgcn_ctrgc_lds_bytes(int S, int V, int R);
 
@@ -224,37 +215,26 @@ typedef struct tamgcn_ctrgc_desc {
     const float* b4;                /* [S][Cout] */
     const float* A;                 /* [S][V][V]      PA (or the A given to CTRGC.forward) */
     const float* alpha;             /* [1] device scalar */
-    const float* E;                 /* optional (N, S, Cout, V, V) from tamgcn_ctrgc_build_e: fwd / bwd_dx3 then load
-                                     * their E tiles instead of rebuilding them per channel tile; NULL = on chip */
+    const float* E;                 /* (N, S, Cout, V, V) from tamgcn_ctrgc_build_e: fwd / bwd_dx3 load their E tiles from it */
 } tamgcn_ctrgc_desc;
 
 /* E[n,s,c,u,v] = alpha*(W4_s tanh(p_s[n,:,u] - q_s[n,:,v]) + b4_s)[c] + A_s[u,v] for every channel, once per
  * layer and sample (R <= 32): reference models/ctrgcn.py:174-176 (tanh of the pairwise difference, conv4, * alpha + A); pass it as d->E to tamgcn_ctrgc_fwd and tamgcn_ctrgc_bwd_dx3. */
 int tamgcn_ctrgc_build_e(const tamgcn_ctrgc_desc* d, float* E, void* stream);
 
-/* y[n,c,t,u] = sum_s sum_v E_s[n,c,u,v] * (W3_s x + b3_s)[n,c,t,v],
- * E_s = alpha*(W4_s tanh(p_s[u]-q_s[v]) + b4_s) + A_s ; with d->E == NULL E lives only in LDS.
+/* y[n,c,t,u] = sum_s sum_v E_s[n,c,u,v] * (W3_s x + b3_s)[n,c,t,v],  E_s = d->E (V = 20, S in {1, 3}, Cout % 8 == 0;
+ * other joint counts: the tamgcn_ctrgc_tiled_* family below).  d->pq, w4, b4, A, alpha are not read.
  * stats_part (optional): [2][Cout][N] partial (sum y, sum y^2) per sample.
- * x3_out (optional): (N, S*Cout, T, V) receives x3 = W3 x + b3 (the tile is in LDS anyway) so that
- * the backward need not recompute the GEMM; NULL keeps the forward write-minimal. */
+ * x3_out (optional): (N, S*Cout, T, V) receives x3 = W3 x + b3 (the tile is in LDS anyway): the backward's dE
+ * accumulation and the conv3 weight gradient read it; NULL (inference) keeps the forward write-minimal. */
 int tamgcn_ctrgc_fwd(const tamgcn_ctrgc_desc* d, float* y, float* stats_part, float* x3_out, void* stream);
 
-/* dx3[n, s*Cout+c, t, v] = sum_u E_s[n,c,u,v] * dy(n,c,t,u);  db3_part [N][S*Cout] */
+/* dx3[n, s*Cout+c, t, v] = sum_u E_s[n,c,u,v] * dy(n,c,t,u);  db3_part [N][S*Cout];  E_s = d->E, d->w3 / b3 not read */
 int tamgcn_ctrgc_bwd_dx3(const tamgcn_ctrgc_desc* d, const tamgcn_src* dy,
                          float* dx3, float* db3_part, void* stream);
 
-/* dE_s[n,c,u,v] = sum_t dy(n,c,t,u) * x3_s[n,c,t,v] (x3 recomputed on chip, never stored) pushed
- * through E's definition:
- *   dA_part     [N*nct][S][V][V]   (sum over the block's channels)
- *   dw4_part    [N][S][Cout][R], db4_part [N][S][Cout], dalpha_part [N*nct]
- *   dpq         [S*2*R][N][V]      accumulated with float atomics: zero it first
- * nct = Cout/16 channel tiles. */
-int tamgcn_ctrgc_bwd_de(const tamgcn_ctrgc_desc* d, const tamgcn_src* dy,
-                        float* dA_part, float* dw4_part, float* db4_part, float* dalpha_part,
-                        float* dpq, void* stream);
-
-/* The same chain (autograd of reference models/ctrgcn.py:172-177 w.r.t. PA, alpha, conv4, conv1/conv2 outputs) when
- * tamgcn_ctrgc_fwd kept x3 (x3_out), as two launches:
+/* dE_s[n,c,u,v] = sum_t dy(n,c,t,u) * x3_s[n,c,t,v] pushed through E's definition (autograd of reference
+ * models/ctrgcn.py:172-177 w.r.t. PA, alpha, conv4, conv1/conv2 outputs), from the x3 tamgcn_ctrgc_fwd kept (x3_out), as two launches:
  *   _de_acc   dE (N, S, Cout, V, V) = sum_t dy(n,c,t,u) * x3[n, s*Cout+c, t, v]     (streaming, HBM-bound)
  *   _de_tail  one workgroup per (n, s, channel group g of `groups`): dA_part [N*groups][S][V][V],
  *             dw4_part [N][S][Cout][R], db4_part [N][S][Cout], dalpha_part [N*S*groups],

@@ -76,8 +76,6 @@ SIGNATURES = {
     'tamgcn_ctrgc_lds_bytes': (_i, [_i, _i, _i]),
     'tamgcn_get_split_mode': (_i, []),
     'tamgcn_set_split_mode': (_i, [_i]),
-    'tamgcn_set_split3_fwd': (_i, [_i]),
-    'tamgcn_set_rows128': (_i, [_i]),
     'tamgcn_conv_nparts': (_i, [C.POINTER(ConvDesc)]),
     'tamgcn_conv': (_i, [C.POINTER(ConvDesc), _p]),
     'tamgcn_wgrad_max_split': (_i, [C.POINTER(WgradDesc)]),
@@ -98,7 +96,6 @@ SIGNATURES = {
     'tamgcn_ctrgc_build_e': (_i, [C.POINTER(CtrgcDesc), _p, _p]),
     'tamgcn_ctrgc_fwd': (_i, [C.POINTER(CtrgcDesc), _p, _p, _p, _p]),
     'tamgcn_ctrgc_bwd_dx3': (_i, [C.POINTER(CtrgcDesc), _SP, _p, _p, _p]),
-    'tamgcn_ctrgc_bwd_de': (_i, [C.POINTER(CtrgcDesc), _SP, _p, _p, _p, _p, _p, _p]),
     'tamgcn_ctrgc_bwd_de_acc': (_i, [C.POINTER(CtrgcDesc), _SP, _p, _p, _p]),
     'tamgcn_ctrgc_bwd_de_tail': (_i, [C.POINTER(CtrgcDesc), _p, _p, _p, _p, _p, _p, _i, _p]),
     'tamgcn_ctrgc_tiled_supported': (_i, [_i]),

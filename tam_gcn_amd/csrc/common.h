@@ -13,12 +13,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------
 void tamgcn_set_error(const char* fmt, ...);
 void tamgcn_note_kernel(const char* fmt, ...);   // symbol of the kernel the last ABI call launched (per thread)
-int tamgcn_split3_fwd(void);                     // three-term (fp32-exact) split in the forward 1x1 GEMMs into >= 128 channels
-int tamgcn_split64(void);
-int tamgcn_rows128(void);        // forward 1x1 convs into >= 128 channels on the 128-row exact-fp32 tile (TAMGCN_ROWS128, default 0: measured slower)
-int tamgcn_wgrad_taps(void);     // k x 1 weight gradients on the LDS-DMA kernel (TAMGCN_WGRAD_TAPS, default 1)                        // two-term split data gradients on 64-row tiles (C = 64 layers)
-int tamgcn_split_mode(void);                     // TAMGCN_SPLIT_BF16: 0 = exact fp32-input MFMA everywhere; 1 (default) = split-fp32 on the bf16 matrix cores in the
-                                                 // weight-gradient GEMMs (their results never feed an activation); 2 = also the forward x3 GEMM
+int tamgcn_wgrad_taps(void);     // k x 1 weight gradients on the LDS-DMA kernel (TAMGCN_WGRAD_TAPS, default 1)
+int tamgcn_split_mode(void);     // TAMGCN_SPLIT_BF16: 0 = exact fp32-input MFMA everywhere; 1 (default) = two-term split-fp32 on the bf16 matrix
+                                 // cores in the BACKWARD GEMMs (weight gradients, data gradients into >= 128 channels): their
+                                 // results never decide a ReLU mask, the 4.5e-6 relative error stays a linear perturbation
 
 #define TG_CHECK(cond, ...)                         \
     do {                                            \
@@ -137,35 +135,6 @@ __device__ __forceinline__ void split_bf16x8(const f32x4& v0, const f32x4& v1, b
 __device__ __forceinline__ f32x4 mfma_split(const bf16x8_t& ah, const bf16x8_t& al, const bf16x8_t& bh, const bf16x8_t& bl, f32x4 c) {
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
-}
-
-// Three-term split: x = hi + mid + lo, each bf16, captures all 24 mantissa bits of an fp32 value; the six products
-// hh, hm, mh, hl, lh, mm (dropped: ml, lm, ll <= 2^-24 relative) reproduce the fp32 product to ~1.2e-7 relative, i.e. fp32
-// rounding level -- unlike the two-term form (4.5e-6) this is safe in ACTIVATION-producing GEMMs (no extra ReLU-mask
-// flips) -- at 6 x 16 cycles per K = 32 step against 8 x 32 for the fp32-input MFMA (2.67x).  ~5.5 VALU per element.
-__device__ __forceinline__ void split3_bf16x8(const f32x4& v0, const f32x4& v1, bf16x8_t& hi, bf16x8_t& mid, bf16x8_t& lo) {
-    u32x4_t h, m, l;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        f32x2_t x = {p < 2 ? v0[2 * p] : v1[2 * p - 4], p < 2 ? v0[2 * p + 1] : v1[2 * p - 3]};
-        h[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2_t));
-        f32x2_t r1 = {x[0] - __uint_as_float(h[p] << 16), x[1] - __uint_as_float(h[p] & 0xffff0000u)};
-        m[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2_t));
-        f32x2_t r2 = {r1[0] - __uint_as_float(m[p] << 16), r1[1] - __uint_as_float(m[p] & 0xffff0000u)};
-        l[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2_t));
-    }
-    hi = __builtin_bit_cast(bf16x8_t, h);
-    mid = __builtin_bit_cast(bf16x8_t, m);
-    lo = __builtin_bit_cast(bf16x8_t, l);
-}
-__device__ __forceinline__ f32x4 mfma_split3(const bf16x8_t& ah, const bf16x8_t& am, const bf16x8_t& al,
-                                             const bf16x8_t& bh, const bf16x8_t& bm, const bf16x8_t& bl, f32x4 c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);      // small terms first
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, c, 0, 0, 0);
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
 }
 

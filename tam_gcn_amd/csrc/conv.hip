@@ -964,8 +964,7 @@ __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs
 #pragma unroll
             for (int e = 0; e < 8; ++e) { cs[e] = cc1[4 * e]; c0[e] = c < nchk ? cf[2 * K + k0 + 4 * e + kq] : 0.f; }
         }
-        bf16x8_t ah[GS_MT], am[GS_MT], al[GS_MT];
-        float af[TERMS == 1 ? GS_MT : 1][8];                       // TERMS == 1: the A values themselves (exact fp32-input MFMA)
+        bf16x8_t ah[GS_MT], al[GS_MT];
 #pragma unroll
         for (int mt = 0; mt < GS_MT; ++mt) {
             f32x4 v0, v1;
@@ -984,35 +983,17 @@ __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs
                     v0[e] *= cs[e]; v1[e] *= cs[e + 4];
                 }
             }
-            if constexpr (TERMS == 1) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { af[mt][e] = v0[e]; af[mt][e + 4] = v1[e]; }
-            } else if constexpr (TERMS == 3) split3_bf16x8(v0, v1, ah[mt], am[mt], al[mt]);
-            else split_bf16x8(v0, v1, ah[mt], al[mt]);
+            split_bf16x8(v0, v1, ah[mt], al[mt]);
         }
 #pragma unroll
         for (int cc = 0; cc < G_CWT; ++cc) {
             f32x4 v0, v1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v0[e] = st[(4 * e + kq) * LB + bslot[cc]]; v1[e] = st[(4 * (e + 4) + kq) * LB + bslot[cc]]; }
-            if constexpr (TERMS == 1) {                           // lane (j, kq) holds k = 4e + kq: step e of eight K = 4 MFMAs
+            bf16x8_t bh, bl;
+            split_bf16x8(v0, v1, bh, bl);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float bv = e < 4 ? v0[e & 3] : v1[e & 3];
-#pragma unroll
-                    for (int mt = 0; mt < GS_MT; ++mt) acc[mt][cc] = mfma16(af[mt][e], bv, acc[mt][cc]);
-                }
-            } else if constexpr (TERMS == 3) {
-                bf16x8_t bh, bm, bl;
-                split3_bf16x8(v0, v1, bh, bm, bl);
-#pragma unroll
-                for (int mt = 0; mt < GS_MT; ++mt) acc[mt][cc] = mfma_split3(ah[mt], am[mt], al[mt], bh, bm, bl, acc[mt][cc]);
-            } else {
-                bf16x8_t bh, bl;
-                split_bf16x8(v0, v1, bh, bl);
-#pragma unroll
-                for (int mt = 0; mt < GS_MT; ++mt) acc[mt][cc] = mfma_split(ah[mt], al[mt], bh, bl, acc[mt][cc]);
-            }
+            for (int mt = 0; mt < GS_MT; ++mt) acc[mt][cc] = mfma_split(ah[mt], al[mt], bh, bl, acc[mt][cc]);
         }
     }
 
@@ -1171,44 +1152,18 @@ extern "C" int tamgcn_conv(const tamgcn_conv_desc* d, void* stream) {
     const bool aligned16 = (((uintptr_t)d->src.x1 | (uintptr_t)(d->src.x2 ? d->src.x2 : d->src.x1) | (uintptr_t)d->w) & 15) == 0;
     const bool glds = p.vec && p.flat && d->K % 16 == 0 && p.LB >= 64 && p.LB <= G_PBMAX && (p.LB & 3) == 0 &&
                       aligned16 && (long long)d->K * d->T_in * d->V < (1LL << 30);
-    // tiles on the bf16 matrix cores, operands split in registers (linear prologue only: it folds into the weights):
-    //   backward (w[k][m]): two-term split, no moments, 128-row tiles into >= 128 channels, 64-row tiles into 64;
-    //   forward (w[m][k], opt-in): three-term split (fp32-exact), with moments, 128-row tiles.
-    const int bmt = d->M >= 128 ? 128 : 64;
-    const size_t lds_split = sizeof(float) * ((size_t)GS_NST * (GS_BK * G_PBMAX + GS_BK * bmt) + 3 * (size_t)d->K + 2 * 4 * BM + bmt);
-    const bool big_ok = glds && tamgcn_split_mode() >= 1 && d->src.act == 0 && d->M >= 64 && d->M % 4 == 0 && d->K % GS_BK == 0 &&
-                        lds_split <= 160 * 1024 && !d->post_coef;
-    const bool big = big_ok && d->wmode == 1 && !d->stats_part && (d->M >= 128 || tamgcn_split64());
-    const bool big3 = big_ok && d->wmode == 0 && d->M >= 128 && tamgcn_split3_fwd();
-    // exact fp32-input MFMA on the same 128-row tile (forward 1x1 convs into >= 128 channels with a linear operand): half the
-    // activation traffic per flop of the 64-row kernel -- opt-in: one workgroup per CU on the two-stage ring exposes every
-    // stall, measured 0.32 of the fp32 MFMA peak against the 64-row kernel's 0.35-0.45 (NTU step 186 vs 177 ms)
-    const bool big1 = glds && !big3 && d->wmode == 0 && d->M >= 128 && d->src.act == 0 && d->M % 4 == 0 && d->K % GS_BK == 0 &&
-                      lds_split <= 160 * 1024 && !d->post_coef && tamgcn_rows128();
-    if (big || big3 || big1) {
-        const int nmt = ceil_div(d->M, bmt);
+    // data gradients into >= 128 channels: 128-row tiles on the bf16 matrix cores, operands split in registers into a
+    // two-term bf16 pair (linear prologue only: it folds into the weights); no moments
+    const size_t lds_split = sizeof(float) * ((size_t)GS_NST * (GS_BK * G_PBMAX + GS_BK * 128) + 3 * (size_t)d->K + 2 * 4 * BM + 128);
+    const bool big = glds && tamgcn_split_mode() >= 1 && d->src.act == 0 && d->M >= 128 && d->M % 4 == 0 && d->K % GS_BK == 0 &&
+                     lds_split <= 160 * 1024 && !d->post_coef && d->wmode == 1 && !d->stats_part;
+    if (big) {
+        const int nmt = ceil_div(d->M, 128);
         const unsigned nblk = (unsigned)(d->N * p.ntt * nmt);
-        if (big1) {
-            static tg_devmask f7 = 0;
-            tg_allow_lds((const void*)conv1x1_glds_split_kernel<1, true, 4>, 160 * 1024, &f7);
-            hipLaunchKernelGGL((conv1x1_glds_split_kernel<1, true, 4>), dim3(nblk), dim3(G_NT), lds_split, (hipStream_t)stream, a, p.ntt, nmt);
-            tamgcn_note_kernel("conv1x1_glds_split_kernel<1, true, 4>");   // TERMS = 1: no split, exact fp32 (rows128)
-        } else if (big3) {
-            static tg_devmask f3 = 0;
-            tg_allow_lds((const void*)conv1x1_glds_split_kernel<3, true, 4>, 160 * 1024, &f3);
-            hipLaunchKernelGGL((conv1x1_glds_split_kernel<3, true, 4>), dim3(nblk), dim3(G_NT), lds_split, (hipStream_t)stream, a, p.ntt, nmt);
-            tamgcn_note_kernel("conv1x1_glds_split_kernel<3, true, 4>");
-        } else if (bmt == 128) {
-            static tg_devmask fs = 0;
-            tg_allow_lds((const void*)conv1x1_glds_split_kernel<2, false, 4>, 160 * 1024, &fs);
-            hipLaunchKernelGGL((conv1x1_glds_split_kernel<2, false, 4>), dim3(nblk), dim3(G_NT), lds_split, (hipStream_t)stream, a, p.ntt, nmt);
-            tamgcn_note_kernel("conv1x1_glds_split_kernel<2, false, 4>");
-        } else {
-            static tg_devmask f6 = 0;
-            tg_allow_lds((const void*)conv1x1_glds_split_kernel<2, false, 2>, 160 * 1024, &f6);
-            hipLaunchKernelGGL((conv1x1_glds_split_kernel<2, false, 2>), dim3(nblk), dim3(G_NT), lds_split, (hipStream_t)stream, a, p.ntt, nmt);
-            tamgcn_note_kernel("conv1x1_glds_split_kernel<2, false, 2>");
-        }
+        static tg_devmask fs = 0;
+        tg_allow_lds((const void*)conv1x1_glds_split_kernel<2, false, 4>, 160 * 1024, &fs);
+        hipLaunchKernelGGL((conv1x1_glds_split_kernel<2, false, 4>), dim3(nblk), dim3(G_NT), lds_split, (hipStream_t)stream, a, p.ntt, nmt);
+        tamgcn_note_kernel("conv1x1_glds_split_kernel<2, false, 4>");
     } else if (glds) {
         const int nmt = ceil_div(d->M, G_BMT);
         const unsigned nblk = (unsigned)(d->N * p.ntt * nmt);
@@ -1938,6 +1893,11 @@ extern "C" int tamgcn_wgrad(const tamgcn_wgrad_desc* d, void* stream) {
         if (rc) return rc;
         TG_LAUNCH_CHECK("tamgcn_wgrad");
         return 0;
+    }
+    if (d->KT == 1) {        // register-staged 1x1 form: one frame of a 128-row tile must fit the prefetch slots (V = 64: 64-row tiles)
+        const int per_row = (d->V + 3) / 4;
+        if (wmt == 4 && 128 * per_row > WG_NPF * NTHREADS) wmt = 2;
+        if (wkt == 4 && 128 * per_row > WG_NPF * NTHREADS) wkt = 2;
     }
     switch (d->KT) {
         case 1:

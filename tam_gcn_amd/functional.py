@@ -28,13 +28,6 @@ from .ops import S, RELU
 _SIDE = {}
 _SIDE_LOCK = threading.Lock()
 USE_SIDE_STREAMS = os.environ.get('TAMGCN_SIDE_STREAMS', '1') != '0'
-# keep x3 = conv3(x) from the forward for the backward (3 x one activation per block, ~3 GB at batch 256)
-# instead of recomputing the GEMM there; TAMGCN_KEEP_X3=0 trades the memory back for time
-KEEP_X3 = os.environ.get('TAMGCN_KEEP_X3', '1') != '0'
-# build E = alpha*(W4 tanh(p-q) + b4) + A once per layer into HBM (N*S*Cout*V*V floats) and let the CTRGC forward /
-# backward load their tiles, instead of every 16-channel tile rebuilding tanh(p-q) on chip; TAMGCN_GLOBAL_E=0 disables
-GLOBAL_E = os.environ.get('TAMGCN_GLOBAL_E', '1') != '0'
-
 
 def _side_streams(device, main, k):
     """The k side streams that belong to MAIN stream `main` of `device`.
@@ -70,12 +63,53 @@ def _side_streams(device, main, k):
     return got
 
 
+# Streams a caller runs whole models on, beside other models on other streams (model_stream()).  Their blocks' branches run
+# in order on that stream: the concurrency comes from the models, and HIP (ROCm 7.2) faults inside hipStreamEndCapture --
+# a segmentation fault, not an error code -- when a stream that JOINED a capture forks further streams (a two-level
+# fork: capture stream -> model stream -> side streams), while one-level forks capture fine.  Found by bisection
+# (tools/stream_capture_check.py, profiles/r03_stream_capture_bisect.txt): plain torch modules on two forked streams
+# capture; this model on a forked stream captures with the side streams off and faults with them on, forward alone included.
+_MODEL_STREAMS = set()
+_CAPTURE_ORIGINS = set()
+
+
+@contextlib.contextmanager
+def model_stream(stream):
+    """``with model_stream(s): loss = criterion(model(x), y)`` -- run a model (and, through autograd, its backward) on
+    stream ``s`` beside other models on other streams.  Like ``torch.cuda.stream(s)``, and registers ``s`` so that the
+    blocks under it do not fork side streams of their own (see _MODEL_STREAMS)."""
+    _MODEL_STREAMS.add((stream.device.index, stream.cuda_stream))
+    with torch.cuda.stream(stream):
+        yield stream
+
+
+def allow_side_streams_in_capture(stream):
+    """Declare ``stream`` the ORIGIN of a HIP-graph capture (``torch.cuda.graph(g, stream=stream)``): blocks then fork their
+    side streams from it during the capture.  torch's default capture stream is recognised without this."""
+    _CAPTURE_ORIGINS.add((stream.device.index, stream.cuda_stream))
+
+
+def _side_ok(device, main):
+    if not USE_SIDE_STREAMS:
+        return False
+    key = (device.index, main.cuda_stream)
+    if key in _MODEL_STREAMS:
+        return False
+    if torch.cuda.is_current_stream_capturing():
+        # Only the stream the capture began on may fork (one level).  That stream cannot be asked from HIP; torch's
+        # own capture stream and the declared origins are known, anything else runs its branches in order.
+        dcs = getattr(torch.cuda.graph, 'default_capture_stream', None)
+        if not ((dcs is not None and dcs.cuda_stream == main.cuda_stream) or key in _CAPTURE_ORIGINS):
+            return False
+    return True
+
+
 class Fork:
     """with Fork(device, k) as f:  f.on(i) -> context running on side stream i; joins on exit."""
 
     def __init__(self, device, k=2):
         self.main = torch.cuda.current_stream(device)
-        self.side = _side_streams(device, self.main, k) if USE_SIDE_STREAMS else []
+        self.side = _side_streams(device, self.main, k) if _side_ok(device, self.main) else []
         self.used = set()
 
     def on(self, i):
@@ -249,9 +283,12 @@ def gcn_forward(x, P, training, save):
     xbar = ops.tmean(xs, Cin)                                             # (Cin, N, V)
     pq, _ = ops.conv(S(xbar.view(1, Cin, N, V)), K=Cin, w=P.W12, bias=P.B12, M=S_ * 2 * R)
     pq = pq.view(S_ * 2 * R, N, V)
-    E = ops.ctrgc_build_E(xs, pq, P.W3, P.B3, P.W4, P.B4, P.PA, P.alpha, Cin, Cout, S_, R) if ((GLOBAL_E or ops.ctrgc_tiled(V)) and R <= 32) else None
+    # E = alpha*(W4 tanh(p_u - q_v) + b4) + A for every channel, once per layer (N*S*Cout*V*V floats: 1.7 GB over the model at
+    # 256 clips); the forward and the dx3 backward load their tiles of it.  x3 = conv3(x) leaves the forward kernel too
+    # (its tile is in LDS anyway; 3 activations per block) for the backward's dE accumulation and conv3 weight gradient.
+    E = ops.ctrgc_build_E(xs, pq, P.W3, P.B3, P.W4, P.B4, P.PA, P.alpha, Cin, Cout, S_, R)
     y_pre, ypart, x3 = ops.ctrgc_fwd(xs, pq, P.W3, P.B3, P.W4, P.B4, P.PA, P.alpha, Cin, Cout, S_, R, stats=training,
-                                     keep_x3=save and KEEP_X3, E=E)
+                                     keep_x3=save, E=E)
     fk.__exit__()                                      # join: d_pre is needed now
     if ev is not None:
         coef_y, save_y = ev['y']
@@ -711,19 +748,22 @@ class CTRGCFn(_Fn):
         xbar = ops.tmean(xs, Cin)
         pq, _ = ops.conv(S(xbar.view(1, Cin, N, V)), K=Cin, w=W12, bias=B12, M=2 * R)
         pq = pq.view(2 * R, N, V)
-        y, _, _ = ops.ctrgc_fwd(xs, pq, W3, b3, W4, b4.reshape(1, Cout), A3, al, Cin, Cout, 1, R, stats=False)
-        ctx.sv = (x, xbar, pq, W12, W3, b3, W4, b4.reshape(1, Cout), A3, al)
+        save = _needs(ctx)
+        E = ops.ctrgc_build_E(xs, pq, W3, b3, W4, b4.reshape(1, Cout), A3, al, Cin, Cout, 1, R)
+        y, _, x3 = ops.ctrgc_fwd(xs, pq, W3, b3, W4, b4.reshape(1, Cout), A3, al, Cin, Cout, 1, R, stats=False, keep_x3=save, E=E)
+        ctx.sv = (x, xbar, pq, W12, W3, b3, W4, b4.reshape(1, Cout), A3, al, E, x3) if save else None
         ctx.shapes = (A.shape, alpha.shape, w1.shape, w3.shape, w4.shape)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, xbar, pq, W12, W3, b3, W4, b4, A3, al = ctx.sv
+        x, xbar, pq, W12, W3, b3, W4, b4, A3, al, E, x3 = ctx.sv
+        ctx.sv = None
         N, Cin, T, V = x.shape
         Cout, R = W3.shape[0], W4.shape[2]
         xs = S(x)
         dx3, db3, dA, dW4, db4, dal, dpq = ops.ctrgc_bwd(xs, pq, W3, b3, W4, b4, A3, al, Cin, Cout, 1, R,
-                                                         S(dy.contiguous()))
+                                                         S(dy.contiguous()), x3=x3, E=E)
         dpq4 = S(dpq.view(1, 2 * R, N, V))
         dW12 = ops.wgrad(dpq4, S(xbar.view(1, Cin, N, V)), M=2 * R, K=Cin)
         dB12 = dpq.sum((1, 2))
@@ -900,7 +940,8 @@ class StGcnFn(_Fn):
         W3, Ae = w3.reshape(w3.shape[0], Cin), Ae.contiguous()
         a = _stgcn_ctrgc_args(x, Ae, W3, b3, Cout)
         cargs = (xs, a['pq'], W3, b3, a['w4'], a['b4'], a['A'], a['alpha'], Cin, Cout, a['K'], a['R'])
-        y_pre, ypart, x3 = ops.ctrgc_fwd(*cargs, stats=training, keep_x3=save and KEEP_X3)
+        E = ops.ctrgc_build_E(*cargs)                    # alpha = 0: E[n, k, c] = (A * importance)[k]^T for every sample and channel
+        y_pre, ypart, x3 = ops.ctrgc_fwd(*cargs, stats=training, keep_x3=save, E=E)
         cnt1 = N * T * V
         coef1, save1 = _coef(Cout, x)
         bn1.fwd(ypart, 0, cnt1, training, coef1, save1, 0)
@@ -925,7 +966,7 @@ class StGcnFn(_Fn):
             res = None
         out = ops.add_act_fwd(S(z_pre, coef=coef2), res, bool(tail), Cout)
         if save:
-            ctx.sv = dict(x=x, Ae=Ae, W3=W3, b3=b3, a=a, x3=x3, y_pre=y_pre, z_pre=z_pre, r_pre=r_pre, out=out, coef1=coef1, save1=save1,
+            ctx.sv = dict(x=x, Ae=Ae, W3=W3, b3=b3, a=a, x3=x3, E=E, y_pre=y_pre, z_pre=z_pre, r_pre=r_pre, out=out, coef1=coef1, save1=save1,
                           coef2=coef2, save2=save2, coef_r=coef_r, save_r=save_r, wt=wt, res_params=res_params, training=training,
                           rmode=rmode, tail=bool(tail))
         ctx.mod = mod
@@ -963,7 +1004,7 @@ class StGcnFn(_Fn):
             dg1, dbe1, _ = bn1.bwd(hp, 0, cnt1, sv['save1'], 0, training, coefb1, 0)
             dy = S(dh, y_pre, coefb1)
             cargs = (xs, a['pq'], W3, b3, a['w4'], a['b4'], a['A'], a['alpha'], Cin, Cout, a['K'], a['R'], dy)
-            dx3, db3 = ops.ctrgc_bwd_dx3(*cargs)
+            dx3, db3 = ops.ctrgc_bwd_dx3(*cargs, E=sv['E'])
             dA, _, _, _, _ = ops.ctrgc_bwd_de(*cargs, x3=sv['x3'])
             dw3 = ops.wgrad(S(dx3), xs, M=a['K'] * Cout, K=Cin)
             gres = []

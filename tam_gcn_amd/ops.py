@@ -347,22 +347,19 @@ def _ctrgc_desc(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, E=None):
     return d
 
 
-# V = 20 on the unfused MFMA route as an experiment (the fused LDS-resident kernels are the default there)
-STREAM_V20 = os.environ.get('TAMGCN_CTRGC_MFMA', '0') == '1'
-
-
 def ctrgc_route(V):
-    """'fused'  V = 20 (25 if the streaming kernels are disabled): LDS-resident E tiles, x3 GEMM + VALU aggregation in one kernel;
+    """'fused'  V = 20: LDS-resident E tiles, x3 GEMM + VALU aggregation in one kernel;
     'stream' V = 25: x3 = W3 x through the pointwise GEMM (kept in HBM), aggregation / dE accumulation on MFMA with the joints padded
-             to 32 in LDS, E and the dE tail from the LDS-resident family (2.5x the fused V = 25 geometry, which fits only 4
-             frames per chunk beside its 120 KB of E tiles);
+             to 32 in LDS, E and the dE tail from the per-(n, subset) kernels of the fused family;
     'tiled'  V in {32, 64}: the same with tiled E / tail kernels (E of one channel is 48 KB at V = 64)."""
     k = _lib_().tamgcn_ctrgc_tiled_supported(int(V))
     if k == 1:
         return 'tiled'
-    if k == 2 and (V != 20 or STREAM_V20) and os.environ.get('TAMGCN_CTRGC_STREAM', '1') != '0':
+    if k == 2 and V != 20:
         return 'stream'
-    return 'fused'
+    if V == 20:
+        return 'fused'
+    raise RuntimeError(f'tam_gcn_amd: CTRGC is built for V in {{20, 25, 32, 64}} joints, got V = {V}')
 
 
 def ctrgc_tiled(V):
@@ -371,8 +368,10 @@ def ctrgc_tiled(V):
 
 
 def ctrgc_build_E(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R):
-    """E (N, S, Cout, V, V) for every channel, once per layer; hand it to ctrgc_fwd / ctrgc_bwd_dx3 (R <= 32)."""
+    """E (N, S, Cout, V, V) for every channel, once per layer; hand it to ctrgc_fwd / ctrgc_bwd_dx3."""
     N, _, T, V = x.x1.shape
+    if R > 32 or R % 4:
+        raise RuntimeError(f'tam_gcn_amd: CTRGC with R = {R} rel-channels is not built (multiples of 4 up to 32: in_channels <= 256 + 7)')
     d = _ctrgc_desc(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R)
     E = empty(N, S, Cout, V, V, like=x.x1)
     if ctrgc_route(V) == 'tiled':
@@ -411,6 +410,9 @@ def ctrgc_fwd(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, stats, keep_x3=F
         if stats and len(chunks) > 1:
             part = torch.cat(parts, dim=2)
         return y, part, (x3 if keep_x3 else None)
+    if E is None:
+        E = ctrgc_build_E(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R)
+        d.E = _ptr(E)
     x3 = empty(N, S * Cout, T, V, like=x.x1) if keep_x3 else None
     _lib.check(_lib_().tamgcn_ctrgc_fwd(C.byref(d), _ptr(y), _ptr(part), _ptr(x3), _stream()), 'tamgcn_ctrgc_fwd')
     return y, part, x3
@@ -432,16 +434,17 @@ def ctrgc_bwd_dx3(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy, E=None, 
             _lib.check(_lib_().tamgcn_ctrgc_tiled_agg_bwd(C.byref(d), C.byref(dyc), _ptr(E[n0:n1]), _ptr(dx3[n0:n1]), _ptr(db3_part[n0:n1]),
                                                           _stream()), 'tamgcn_ctrgc_tiled_agg_bwd')
     else:
+        if E is None:
+            E = ctrgc_build_E(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R)
+            d.E = _ptr(E)
         _lib.check(_lib_().tamgcn_ctrgc_bwd_dx3(C.byref(d), C.byref(dyc), _ptr(dx3), _ptr(db3_part), _stream()),
                    'tamgcn_ctrgc_bwd_dx3')
     return dx3, (reduce_sum(db3_part, N, chunks=[(Cout,)] * S) if per_subset else reduce_sum(db3_part, N))
 
 
 def ctrgc_bwd_de(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy, x3=None, per_subset=False):
-    """The dE chain: dA [S,V,V], dw4 [S,Cout,R], db4 [S,Cout], dalpha [1], dpq [S*2*R,N,V].
-
-    With x3 (kept by ctrgc_fwd) and R <= 32: a streaming accumulation of dE plus one per-(n, s)
-    tail launch; otherwise the fused kernel that recomputes x3 on chip."""
+    """The dE chain: dA [S,V,V], dw4 [S,Cout,R], db4 [S,Cout], dalpha [1], dpq [S*2*R,N,V]: a streaming accumulation of
+    dE from dy and the x3 ctrgc_fwd kept (recomputed by one pointwise GEMM if it was not), then one per-(n, s) tail launch."""
     N, _, T, V = x.x1.shape
     d = _ctrgc_desc(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R)
     dyc = dy.c()
@@ -471,44 +474,32 @@ def ctrgc_bwd_de(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy, x3=None, 
         return (reduce_sum(dA_part, N), reduce_sum(dw4_part, N * NUC, chunks=[(Cout, R, 1, 1)] * S if ps else None),
                 reduce_sum(db4_part, N * NUC, chunks=[(Cout,)] * S if ps else None), reduce_sum(dal_part, N * S * NUC),
                 reduce_sum(dpq, NUC, immediate=True))
-    if route == 'stream' and R > 32:
-        raise RuntimeError('tam_gcn_amd: CTRGC with R > 32 rel-channels is not built for V = %d' % V)
-    if (x3 is not None or dE is not None) and R <= 32:
-        if dE is None:
-            dE = empty(N, S, Cout, V, V, like=like)
-            _lib.check(_lib_().tamgcn_ctrgc_bwd_de_acc(C.byref(d), C.byref(dyc), _ptr(x3), _ptr(dE), _stream()),
-                       'tamgcn_ctrgc_bwd_de_acc')
-        G = 1                                           # channel groups per (n, subset); the per-workgroup fixed cost (D fill,
-        #                                               dp/dq sums) equals ~1.4 channel chunks, so splitting did not pay (measured)
-        while Cout % (16 * G):
-            G -= 1
-        dA_part = empty(N * G, S, V, V, like=like)
-        dw4_part = empty(N, S, Cout, R, like=like)
-        db4_part = empty(N, S, Cout, like=like)
-        dal_part = empty(N * S * G, 1, like=like)
-        dpq = empty(G, S * 2 * R, N, V, like=like)
-        _lib.check(_lib_().tamgcn_ctrgc_bwd_de_tail(C.byref(d), _ptr(dE), _ptr(dA_part), _ptr(dw4_part), _ptr(db4_part),
-                                                    _ptr(dal_part), _ptr(dpq), G, _stream()), 'tamgcn_ctrgc_bwd_de_tail')
-        dpq = dpq[0] if G == 1 else reduce_sum(dpq, G)
-        ps = per_subset
-        return (reduce_sum(dA_part, N * G), reduce_sum(dw4_part, N, chunks=[(Cout, R, 1, 1)] * S if ps else None),
-                reduce_sum(db4_part, N, chunks=[(Cout,)] * S if ps else None), reduce_sum(dal_part, N * S * G), dpq)
-    nct = Cout // 16
-    dA_part = empty(N * nct, S, V, V, like=like)
+    if R > 32:
+        raise RuntimeError('tam_gcn_amd: CTRGC with R > 32 rel-channels is not built')
+    if dE is None:
+        if x3 is None:                                      # the caller did not keep x3: one more pointwise GEMM
+            x3 = _x3_gemm(x, w3, b3, Cin, Cout, S)
+        dE = empty(N, S, Cout, V, V, like=like)
+        _lib.check(_lib_().tamgcn_ctrgc_bwd_de_acc(C.byref(d), C.byref(dyc), _ptr(x3), _ptr(dE), _stream()),
+                   'tamgcn_ctrgc_bwd_de_acc')
+    G = 1                                               # channel groups per (n, subset); the per-workgroup fixed cost (D fill,
+    #                                                     dp/dq sums) equals ~1.4 channel chunks, so splitting did not pay (measured)
+    dA_part = empty(N * G, S, V, V, like=like)
     dw4_part = empty(N, S, Cout, R, like=like)
     db4_part = empty(N, S, Cout, like=like)
-    dal_part = empty(N * nct, 1, like=like)
-    dpq = torch.zeros(S * 2 * R, N, V, device=like.device, dtype=torch.float32)
-    _lib.check(_lib_().tamgcn_ctrgc_bwd_de(C.byref(d), C.byref(dyc), _ptr(dA_part), _ptr(dw4_part), _ptr(db4_part),
-                                           _ptr(dal_part), _ptr(dpq), _stream()), 'tamgcn_ctrgc_bwd_de')
+    dal_part = empty(N * S * G, 1, like=like)
+    dpq = empty(G, S * 2 * R, N, V, like=like)
+    _lib.check(_lib_().tamgcn_ctrgc_bwd_de_tail(C.byref(d), _ptr(dE), _ptr(dA_part), _ptr(dw4_part), _ptr(db4_part),
+                                                _ptr(dal_part), _ptr(dpq), G, _stream()), 'tamgcn_ctrgc_bwd_de_tail')
+    dpq = dpq[0]
     ps = per_subset
-    return (reduce_sum(dA_part, N * nct), reduce_sum(dw4_part, N, chunks=[(Cout, R, 1, 1)] * S if ps else None),
-            reduce_sum(db4_part, N, chunks=[(Cout,)] * S if ps else None), reduce_sum(dal_part, N * nct), dpq)
+    return (reduce_sum(dA_part, N * G), reduce_sum(dw4_part, N, chunks=[(Cout, R, 1, 1)] * S if ps else None),
+            reduce_sum(db4_part, N, chunks=[(Cout,)] * S if ps else None), reduce_sum(dal_part, N * S * G), dpq)
 
 
-def ctrgc_bwd(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy, x3=None):
+def ctrgc_bwd(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy, x3=None, E=None):
     """Returns dx3 (N,S*Cout,T,V), db3 [S*Cout], dA [S,V,V], dw4 [S,Cout,R], db4 [S,Cout], dalpha [1], dpq [S*2*R,N,V]."""
-    dx3, db3 = ctrgc_bwd_dx3(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy)
+    dx3, db3 = ctrgc_bwd_dx3(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy, E=E)
     dA, dw4, db4, dal, dpq = ctrgc_bwd_de(x, pq, w3, b3, w4, b4, A, alpha, Cin, Cout, S, R, dy, x3)
     return dx3, db3, dA, dw4, db4, dal, dpq
 

@@ -70,7 +70,8 @@ def test_config0_feeder_sample_through_model(tmp_path, golden_models):
         logits = m(x)
         feat, _ = m.extract_feature(x)
     assert tuple(logits.shape) == (1, 10) and tuple(feat.shape) == (1, 256, 13, 20, 1)
-    assert float((logits.cpu() - ref).abs().max()) <= 1e-3
+    err, scale = float((logits.cpu() - ref).abs().max()), max(1.0, float(ref.abs().max()))
+    assert err <= 1e-3 * scale, (err, scale, logits.cpu(), ref)
     assert int(logits.argmax(1)) == int(ref.argmax(1))
     # the batch form the data-parallel step uses gives the same clip
     xb, lab, _ = fd.batch([0])
@@ -203,87 +204,38 @@ def test_config2_four_streams_one_arena_one_bucket():
                 assert torch.equal(sa[k], sb[k]), k
 
 
-def _two_model_step(models, xs, lab, streams):
-    """fwd + CE + bwd of every model, model i on streams[i] (None: the current stream); returns losses."""
-    from tam_gcn_amd.functional import CrossEntropyLoss
-    ce = CrossEntropyLoss()
-    cur = torch.cuda.current_stream()
-    for m in models:
-        for p in m.parameters():
-            p.grad = None
-    losses = []
-    for m, x, st in zip(models, xs, streams):
-        if st is None:
-            losses.append(ce(m(x), lab))
-            continue
-        st.wait_stream(cur)
-        with torch.cuda.stream(st):
-            losses.append(ce(m(x), lab))
-    for st in streams:
-        if st is not None:
-            cur.wait_stream(st)
-    total = losses[0]
-    for l_ in losses[1:]:
-        total = total + l_
-    total.backward()                                        # autograd replays every node on its forward's stream and joins
-    return [l_.detach() for l_ in losses]
+def _run_stream_check(mode, n=4):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-X', 'faulthandler', os.path.join(root, 'tools', 'stream_capture_check.py'), mode, str(n)],
+                       capture_output=True, text=True, timeout=600)
+    return r.returncode, r.stdout, r.stderr
 
 
-def test_models_on_separate_streams_eager_and_captured():
-    """Two (then four) Models, each on its own HIP stream -- forward and, through autograd, backward -- as
-    bench.py --config 4stream runs them: bit-identical to the same step on ONE stream, eagerly and replayed from a HIP
-    graph.  Every main stream owns its side streams (functional._side_streams): blocks of the caching allocator never
-    move between two models' streams."""
-    from tam_gcn_amd import functional as Fn
-    dev = torch.device('cuda:0')
-    nm = 4
-    models = _four_models(dev)
-    x = make_input((4, 3, 32, 20, 1), seed=41).to(dev)
-    lab = make_labels(4, 10, seed=42).to(dev)
-    parent = torch.tensor(BONE_PARENT, dtype=torch.int32, device=dev)
-    xs = [x if n == 'joint' else ops.stream_derive(x, parent, n) for n in STREAMS]
-    state0 = [{k: v.clone() for k, v in m.state_dict().items()} for m in models]
+def test_models_on_separate_streams_eager():
+    """Four Models, each on its own HIP stream -- forward and, through autograd, backward -- as
+    bench.py --config 4stream runs them: bit-identical to the same step on ONE stream.  Every main stream owns its side
+    streams (functional._side_streams): blocks of the caching allocator never move between two models' streams.
+    (Own process: tools/stream_capture_check.py.)"""
+    rc, out, err = _run_stream_check('eager')
+    assert rc == 0 and 'eager: OK' in out, (rc, out[-1500:], err[-3000:])
 
-    def reset():
-        for m, s in zip(models, state0):
-            m.load_state_dict(s)
 
-    def grads():
-        return [[p.grad.clone() for p in m.parameters()] for m in models]
+def test_models_on_separate_streams_captured():
+    """The same step captured into ONE HIP graph and replayed: bit-identical to the eager step.  The models sit on
+    functional.model_stream()s, whose blocks do not fork side streams: a two-level fork inside a capture faults in
+    hipStreamEndCapture (profiles/r03_stream_capture_bisect.txt)."""
+    rc, out, err = _run_stream_check('capture')
+    assert rc == 0 and 'capture: OK' in out, (rc, out[-1500:], err[-3000:])
 
-    ref_loss = _two_model_step(models, xs, lab, [None] * nm)
-    torch.cuda.synchronize()
-    ref_grads = grads()
-    ref_state = [{k: v.clone() for k, v in m.state_dict().items()} for m in models]
-    # eager, one stream per model
-    reset()
-    sts = [torch.cuda.Stream(dev) for _ in range(nm)]
-    loss = _two_model_step(models, xs, lab, sts)
-    torch.cuda.synchronize()
-    assert all(torch.equal(a, b) for a, b in zip(loss, ref_loss))
-    for ga, gb in zip(grads(), ref_grads):
-        assert all(torch.equal(a, b) for a, b in zip(ga, gb))
-    for m, s in zip(models, ref_state):                     # running statistics written through raw pointers
-        assert all(torch.equal(v, s[k]) for k, v in m.state_dict().items())
-    keys = [k for k in Fn._SIDE if k[0] == dev.index]
-    assert {s.cuda_stream for s in sts} <= {k[1] for k in keys}    # each model stream got its own side pool (empty if torch's
-    handles = [s.cuda_stream for k in keys for s in Fn._SIDE[k]]   # 32-stream pool had wrapped around: then it runs in order)
-    assert len(handles) == len(set(handles))                       # no side stream serves two main streams
-    # captured: warm-up on a side stream, capture, replay twice
-    reset()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        closs = _two_model_step(models, xs, lab, sts)
-    cgrads = [[p.grad for p in m.parameters()] for m in models]
-    for _ in range(2):
-        reset()
-        g.replay()
-        torch.cuda.synchronize()
-        assert all(torch.equal(a, b) for a, b in zip(closs, ref_loss))
-        for ga, gb in zip(cgrads, ref_grads):
-            assert all(torch.equal(a, b) for a, b in zip(ga, gb))
-        for m, s in zip(models, ref_state):
-            assert all(torch.equal(v, s[k]) for k, v in m.state_dict().items())
+
+def test_capture_on_a_plain_forked_stream_is_guarded():
+    """A caller that captures a model under a plain torch.cuda.stream(s) forked from the capture stream (not declared
+    through model_stream / allow_side_streams_in_capture): functional._side_ok keeps its blocks from forking during the
+    capture -- the step captures and replays bit-identically instead of taking the process down."""
+    rc, out, err = _run_stream_check('capture_raw', 2)
+    assert rc == 0 and 'capture_raw: OK' in out, (rc, out[-1500:], err[-3000:])
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -12,6 +12,12 @@ from helpers import (MODULE_CASES, COT_SEED, tag_seed, fill_state_, make_input, 
 from params import digest                              # noqa: E402
 
 
+import re                                              # noqa: E402
+
+# conv -> train-mode BatchNorm pairs of the reference modules (models/ctrgcn.py:56-64, 95-123, 183-193, 209-223)
+ZERO_GRAD_BIAS = re.compile(r'(^|\.)(down\.0|offset_conv\.0|branches\.\d\.0|branches\.\d\.3\.conv|residual\.conv|conv)\.bias$')
+
+
 def _cmp(name, got, ref, rel, atol=0.0):
     got = got.detach().cpu().double()
     ref = torch.as_tensor(ref).double()
@@ -70,8 +76,10 @@ def test_module_parity(case, golden_modules):
         assert p.grad is not None, f'no grad for {k}'
         go = sd['m.' + k].grad
         # biases of convs that feed a train-mode BatchNorm have an exactly-zero gradient in exact
-        # arithmetic; the reference produces ~1e-5 rounding noise there, hence the absolute floor
-        if k.endswith('bias') and float(go.abs().max()) < 2e-4:
+        # arithmetic; the reference produces rounding noise there (~1e-5 at T = 8..13, 3.5e-4 at T = 72, V = 64): such a
+        # bias is recognised by its place in the module (a convolution directly followed by a BatchNorm) or by the size
+        # of the reference's own value, and held to an absolute bound
+        if k.endswith('bias') and (ZERO_GRAD_BIAS.search(k) or float(go.abs().max()) < 2e-4):
             assert float(p.grad.abs().max()) < 2e-3, k
             continue
         _cmp(f'grad {k} vs oracle', p.grad, go, REL_G, 2e-5)

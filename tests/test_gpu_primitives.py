@@ -233,26 +233,26 @@ def test_ctrgc_fused_fwd_bwd(shape):
     close(x3k, x3r, 2e-4, 2e-4, 'x3 kept for the backward')
     yg0, _, none = ops.ctrgc_fwd(xs, pq, t(W3), t(B3), t(W4), t(B4), t(A), t(alpha), Cin, Cout, S_, R, stats=False)
     assert none is None and torch.equal(yg0, yg)
-    # E built once in HBM and loaded by the kernels vs E tiles built on chip
+    # E, built once per layer in HBM and loaded by the kernels, against its definition
     Eg = ops.ctrgc_build_E(xs, pq, t(W3), t(B3), t(W4), t(B4), t(A), t(alpha), Cin, Cout, S_, R)
     Er = torch.stack([alpha * (torch.einsum('cr,nruv->ncuv', W4[s], torch.tanh(
         pqr[(2 * s) * R:(2 * s + 1) * R].permute(1, 0, 2).unsqueeze(-1) - pqr[(2 * s + 1) * R:(2 * s + 2) * R].permute(1, 0, 2).unsqueeze(-2)))
         + B4[s][None, :, None, None]) + A[s][None, None] for s in range(S_)], 1)
     close(Eg, Er, 2e-4, 2e-5, 'E')
     yg1, _, _ = ops.ctrgc_fwd(xs, pq, t(W3), t(B3), t(W4), t(B4), t(A), t(alpha), Cin, Cout, S_, R, stats=False, E=Eg)
-    close(yg1, yg, 1e-5, 1e-5, 'ctrgc fwd with E from HBM')
+    assert torch.equal(yg1, yg)                                           # E handed in == E built inside the call
     close(part[0].sum(-1), y.sum((0, 2, 3)), 1e-3, 1e-2, 'stats')
     close(part[1].sum(-1), (y * y).sum((0, 2, 3)), 1e-3, 1e-2, 'stats2')
     dx3, db3, dA, dW4, db4, dal, dpq = ops.ctrgc_bwd(xs, pq, t(W3), t(B3), t(W4), t(B4), t(A), t(alpha),
-                                                     Cin, Cout, S_, R, S(t(cot)))
-    dx3e, db3e = ops.ctrgc_bwd_dx3(xs, pq, t(W3), t(B3), t(W4), t(B4), t(A), t(alpha), Cin, Cout, S_, R, S(t(cot)), E=Eg)
-    close(dx3e, dx3, 1e-5, 1e-5 * float(dx3.abs().max()), 'dx3 with E from HBM')
+                                                     Cin, Cout, S_, R, S(t(cot)), x3=x3k, E=Eg)
+    dx3e, db3e = ops.ctrgc_bwd_dx3(xs, pq, t(W3), t(B3), t(W4), t(B4), t(A), t(alpha), Cin, Cout, S_, R, S(t(cot)))
+    assert torch.equal(dx3e, dx3)                                         # E rebuilt inside the call
     gpq, = torch.autograd.grad((y * cot).sum(), pqr, retain_graph=True)
     sc = lambda g: 2e-4 * (float(g.abs().max()) + 1e-3)
-    # stored-x3 variant of the dE kernel against the recomputing one
+    # the dE chain without the kept x3 (one more pointwise GEMM) against the one that reads it
     for got, ref, nm in zip(ops.ctrgc_bwd_de(xs, pq, t(W3), t(B3), t(W4), t(B4), t(A), t(alpha), Cin, Cout, S_, R,
-                                             S(t(cot)), x3=x3k), (dA, dW4, db4, dal, dpq), ('dA', 'dW4', 'db4', 'dalpha', 'dpq')):
-        close(got, ref.cpu(), 1e-4, 0.25 * sc(ref.cpu()), nm + ' (stored x3)')
+                                             S(t(cot))), (dA, dW4, db4, dal, dpq), ('dA', 'dW4', 'db4', 'dalpha', 'dpq')):
+        close(got, ref.cpu(), 1e-4, 0.25 * sc(ref.cpu()), nm + ' (x3 recomputed)')
     close(dA, A.grad, 1e-3, sc(A.grad), 'dA')
     close(dW4, W4.grad, 1e-3, sc(W4.grad), 'dW4')
     close(db4, B4.grad, 1e-3, sc(B4.grad), 'db4')
@@ -420,65 +420,6 @@ def test_cross_entropy_against_torch():
         loss = CrossEntropyLoss()(lg, lab2)
         loss.backward()
         assert torch.isnan(loss) and float(lg.grad[3].abs().max()) == 0.0
-
-
-def test_three_term_split_forward_gemm_matches_exact_kernels():
-    """conv1x1_glds_split_kernel<3, fwd> (opt-in, TAMGCN_SPLIT3_FWD): six bf16 MFMAs per K = 32 step reproduce the exact
-    fp32-input MFMA kernels to 1e-6 of the output scale, BatchNorm moments included, over one / two sources, partial
-    tiles, V = 20 / 25 / 64."""
-    from tam_gcn_amd import _lib, ops
-    from tam_gcn_amd.ops import S
-    lib = _lib.load()
-    dev = torch.device('cuda:0')
-    g = torch.Generator().manual_seed(0)
-    r = lambda *s: (torch.rand(*s, generator=g) * 2 - 1).to(dev)      # noqa: E731
-    prev = lib.tamgcn_get_split_mode()
-    try:
-        for (N, K, M, T, V, two) in [(4, 64, 128, 7, 20, 0), (4, 128, 128, 7, 20, 1), (4, 256, 256, 4, 20, 1), (3, 64, 192, 13, 20, 0),
-                                     (2, 128, 384, 33, 25, 0), (2, 256, 768, 12, 64, 0)]:
-            x1, x2 = r(N, K, T, V), r(N, K, T, V)
-            coef = torch.stack((r(K) + 1.5, r(K), r(K)))
-            w, b = r(M, K) * K ** -0.5, r(M)
-            src = S(x1, x2, coef) if two else S(x1)
-            lib.tamgcn_set_split_mode(0); lib.tamgcn_set_rows128(0)
-            y0, p0 = ops.conv(src, K=K, w=w, bias=b, M=M, stats=True)
-            assert b'conv1x1_glds_kernel' in lib.tamgcn_last_kernel()
-            lib.tamgcn_set_split_mode(1); lib.tamgcn_set_split3_fwd(1)
-            y1, p1 = ops.conv(src, K=K, w=w, bias=b, M=M, stats=True)
-            assert b'split_kernel<3' in lib.tamgcn_last_kernel()
-            lib.tamgcn_set_split3_fwd(0)
-            assert float((y0 - y1).abs().max()) <= 2e-6 * float(y0.abs().max())
-            assert float((p0.sum(2) - p1.sum(2)).abs().max()) <= 2e-6 * float(p0.sum(2).abs().max())
-            # opt-in: the same exact fp32-input MFMA on the 128-row tile (K % 32 == 0)
-            lib.tamgcn_set_rows128(1)
-            y2, p2 = ops.conv(src, K=K, w=w, bias=b, M=M, stats=True)
-            assert b'split_kernel<1, true, 4>' in lib.tamgcn_last_kernel()
-            a = (coef[0][None, :, None, None] * x1 + coef[1][None, :, None, None] * x2 + coef[2][None, :, None, None]) if two else x1
-            ref = torch.einsum('mk,nktv->nmtv', w.double(), a.double()) + b.double()[None, :, None, None]
-            e64, e128 = float((y0.double() - ref).abs().max()), float((y2.double() - ref).abs().max())
-            # (the linear prologue is folded into the weight fragment there: one more rounding per product)
-            assert e128 <= max(2.0 * e64, 2e-6 * float(ref.abs().max())), (e64, e128)
-            assert float((y0 - y2).abs().max()) <= 2e-6 * float(y0.abs().max())
-            assert float((p0.sum(2) - p2.sum(2)).abs().max()) <= 2e-6 * float(p0.sum(2).abs().max())
-        # the fused CTRGC forward's x3 GEMM takes the same three-term form under the switch (V = 20, Cin % 32 == 0)
-        N, Cin, Cout, T, V, S_, R = 3, 64, 64, 16, 20, 3, 8
-        x, pq = r(N, Cin, T, V), r(S_ * 2 * R, N, V)
-        W3, B3, W4, B4 = r(S_ * Cout, Cin) * Cin ** -0.5, r(S_ * Cout) * 0.1, r(S_, Cout, R) * R ** -0.5, r(S_, Cout) * 0.1
-        A, al = r(S_, V, V) * 0.3, torch.tensor([0.7], device=dev)
-        outs = []
-        for on in (0, 1):
-            lib.tamgcn_set_split_mode(1); lib.tamgcn_set_split3_fwd(on)
-            y, part, x3 = ops.ctrgc_fwd(S(x), pq, W3, B3, W4, B4, A, al, Cin, Cout, S_, R, stats=True, keep_x3=True)
-            assert (b'ctrgc_fwd_split3_kernel' in lib.tamgcn_last_kernel()) == bool(on), lib.tamgcn_last_kernel()
-            outs.append((y, part, x3))
-        (y0, p0, x30), (y1, p1, x31) = outs
-        assert float((x30 - x31).abs().max()) <= 2e-6 * float(x30.abs().max())
-        assert float((y0 - y1).abs().max()) <= 2e-6 * float(y0.abs().max())
-        assert float((p0.sum(2) - p1.sum(2)).abs().max()) <= 2e-6 * float(p0.sum(2).abs().max())
-    finally:
-        lib.tamgcn_set_split3_fwd(0)
-        lib.tamgcn_set_rows128(0)
-        lib.tamgcn_set_split_mode(prev)
 
 
 @pytest.mark.parametrize('shape', [(3, 64, 64, 16, 20, 5, 1), (2, 32, 64, 13, 25, 5, 2), (2, 64, 48, 10, 64, 5, 2)])

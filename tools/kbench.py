@@ -75,26 +75,22 @@ if not only or 'ctrgc' in only:
         pq = r(S_ * 2 * R, N, V)
         W3 = r(S_ * Cout, Cin) * 0.1; B3 = r(S_ * Cout); W4 = r(S_, Cout, R) * 0.1; B4 = r(S_, Cout)
         A = r(S_, V, V) * 0.1; al = torch.tensor([0.5], device=dev)
-        us = timeit(lambda: ops.ctrgc_fwd(S(x), pq, W3, B3, W4, B4, A, al, Cin, Cout, S_, R, stats=True))
         fl = N * S_ * (2.0 * Cin * Cout * T * V + 2.0 * R * Cout * V * V + 2.0 * Cout * T * V * V)
-        rep('ctrgc_fwd ' + nm, us, 4.0 * N * T * V * (Cin + Cout), fl)
-        us = timeit(lambda: ops.ctrgc_fwd(S(x), pq, W3, B3, W4, B4, A, al, Cin, Cout, S_, R, stats=True, keep_x3=True))
-        rep('ctrgc_fwd +x3 store ' + nm, us, 4.0 * N * T * V * (Cin + 4 * Cout), fl)
         # the training configuration: E built once per layer, forward loads its tiles and keeps x3
         us = timeit(lambda: ops.ctrgc_build_E(S(x), pq, W3, B3, W4, B4, A, al, Cin, Cout, S_, R))
         rep('ctrgc_build_e ' + nm, us, 4.0 * N * S_ * Cout * V * V, N * S_ * 2.0 * R * Cout * V * V)
         Eg = ops.ctrgc_build_E(S(x), pq, W3, B3, W4, B4, A, al, Cin, Cout, S_, R)
         us = timeit(lambda: ops.ctrgc_fwd(S(x), pq, W3, B3, W4, B4, A, al, Cin, Cout, S_, R, stats=True, keep_x3=True, E=Eg))
         rep('ctrgc_fwd (E loaded, x3 kept; SURVEY bytes) ' + nm[:14], us, 4.0 * N * T * V * (Cin + Cout), fl)
-        _, _, x3 = ops.ctrgc_fwd(S(x), pq, W3, B3, W4, B4, A, al, Cin, Cout, S_, R, stats=True, keep_x3=True)
+        us = timeit(lambda: ops.ctrgc_fwd(S(x), pq, W3, B3, W4, B4, A, al, Cin, Cout, S_, R, stats=False, E=Eg))
+        rep('ctrgc_fwd (E loaded, no x3 store: inference) ' + nm[:14], us, 4.0 * N * T * V * (Cin + Cout), fl)
+        _, _, x3 = ops.ctrgc_fwd(S(x), pq, W3, B3, W4, B4, A, al, Cin, Cout, S_, R, stats=True, keep_x3=True, E=Eg)
         dy = r(N, Cout, T, V); ypre = r(N, Cout, T, V); cb = r(3, Cout)
         ca = (S(x), pq, W3, B3, W4, B4, A, al, Cin, Cout, S_, R, S(dy, ypre, cb))
         us = timeit(lambda: ops.ctrgc_bwd_dx3(*ca, E=Eg))
         rep('ctrgc_bwd_dx3 ' + nm, us, 4.0 * N * T * V * (2 * Cout + 3 * Cout), N * S_ * (2.0 * R * Cout * V * V + 2.0 * Cout * T * V * V))
-        us = timeit(lambda: ops.ctrgc_bwd_de(*ca))
-        rep('ctrgc_bwd_de recompute ' + nm, us, 4.0 * N * T * V * (Cin + 2 * Cout), fl)
         us = timeit(lambda: ops.ctrgc_bwd_de(*ca, x3=x3))
-        rep('ctrgc_bwd_de stored x3 ' + nm, us, 4.0 * N * T * V * (2 * Cout + 3 * Cout), N * S_ * (2.0 * R * Cout * V * V + 2.0 * Cout * T * V * V))
+        rep('ctrgc_bwd_de (acc + tail) ' + nm, us, 4.0 * N * T * V * (2 * Cout + 3 * Cout), N * S_ * (2.0 * R * Cout * V * V + 2.0 * Cout * T * V * V))
 
 if not only or 'ew' in only:
     for C_, T in [(64, 64), (256, 16)]:

@@ -1,0 +1,175 @@
+"""GPU-box tool and test helper: several Models, each on its own HIP stream (forward and, through autograd, backward),
+eagerly and captured into ONE HIP graph -- the step of `bench.py --config 4stream`.  Runs in its own process (a fault inside
+hipStreamEndCapture would otherwise take the test session down with it) and prints one line per stage.
+
+    python -X faulthandler tools/stream_capture_check.py <mode> [n_models]
+
+modes   eager        n models on n streams, eager; must equal the one-stream step bit for bit
+        capture      the same step captured (torch.cuda.graph) and replayed twice; bit-identical to eager
+        capture_fwd  forward + loss only under capture (no autograd thread)
+        capture_noside   capture with the per-block side streams off (TAMGCN_SIDE_STREAMS=0 semantics)
+        capture_raw  capture with plain torch.cuda.stream(s) instead of functional.model_stream(s): the guard in
+                     functional._side_ok must then keep the model streams from forking (two-level forks fault in HIP)
+        capture_twolevel   the faulting form itself: side streams forced on under the model streams (diagnosis only)
+        capture_one  ONE model on a stream forked from the capture stream
+        capture_relaxed  capture with capture_error_mode='relaxed'
+        toy          two torch.nn.Linear stacks on two streams, forward + backward captured (no tam_gcn_amd kernels)
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+
+import torch                                                             # noqa: E402
+
+mode = sys.argv[1] if len(sys.argv) > 1 else 'capture'
+nm = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+dev = torch.device('cuda:0')
+
+
+def say(msg):
+    print(msg, flush=True)
+
+
+def toy():
+    torch.manual_seed(0)
+    nets = [torch.nn.Sequential(torch.nn.Linear(64, 64), torch.nn.ReLU(), torch.nn.Linear(64, 8)).to(dev) for _ in range(2)]
+    x = torch.randn(16, 64, device=dev)
+    sts = [torch.cuda.Stream(dev) for _ in nets]
+
+    def step():
+        cur = torch.cuda.current_stream()
+        for n_ in nets:
+            for p in n_.parameters():
+                p.grad = None
+        losses = []
+        for n_, st in zip(nets, sts):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                losses.append(n_(x).square().mean())
+        for st in sts:
+            cur.wait_stream(st)
+        (losses[0] + losses[1]).backward()
+        return [l_.detach() for l_ in losses]
+
+    s = torch.cuda.Stream(dev)
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            ref = step()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    say('toy: eager ok')
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = step()
+    say('toy: captured')
+    g.replay()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(out, ref))
+    say('toy: replay ok')
+
+
+def main():
+    if mode == 'toy':
+        return toy()
+    from cases import MODEL_CASES, MODEL_PARAM_SEED
+    from params import fill_state_, make_input, make_labels
+    from tam_gcn_amd import functional as Fn, ops
+    from tam_gcn_amd.functional import CrossEntropyLoss
+    from tam_gcn_amd.feeder.feeder_nucla_gcn import BONE_PARENT
+    from tam_gcn_amd.models import ctrgcn as M
+    if mode == 'capture_noside':
+        Fn.USE_SIDE_STREAMS = False
+    if mode == 'capture_twolevel':
+        Fn._side_ok = lambda device, main: True
+    on_stream = torch.cuda.stream if mode in ('capture_raw', 'capture_twolevel', 'capture_noside') else Fn.model_stream
+    names = ('joint', 'bone', 'motion', 'bone_motion')[:nm]
+    models = torch.nn.ModuleList()
+    for i in range(nm):
+        m = M.Model(**MODEL_CASES[0][1])
+        fill_state_(m.state_dict(), seed=MODEL_PARAM_SEED + i)
+        models.append(m)
+    models = models.to(dev).train()
+    x = make_input((4, 3, 32, 20, 1), seed=41).to(dev)
+    lab = make_labels(4, 10, seed=42).to(dev)
+    parent = torch.tensor(BONE_PARENT, dtype=torch.int32, device=dev)
+    xs = [x if n == 'joint' else ops.stream_derive(x, parent, n) for n in names]
+    state0 = [{k: v.clone() for k, v in m.state_dict().items()} for m in models]
+    ce = CrossEntropyLoss()
+    backward = mode != 'capture_fwd'
+
+    def reset():
+        for m, s in zip(models, state0):
+            m.load_state_dict(s)
+
+    def step(streams):
+        cur = torch.cuda.current_stream()
+        for m in models:
+            for p in m.parameters():
+                p.grad = None
+        losses = []
+        for m, xi, st in zip(models, xs, streams):
+            if st is None:
+                losses.append(ce(m(xi), lab))
+                continue
+            st.wait_stream(cur)
+            with on_stream(st):
+                losses.append(ce(m(xi), lab))
+        for st in streams:
+            if st is not None:
+                cur.wait_stream(st)
+        if backward:
+            total = losses[0]
+            for l_ in losses[1:]:
+                total = total + l_
+            total.backward()                     # autograd replays every node on its forward's stream and joins the leaf streams
+        return [l_.detach() for l_ in losses]
+
+    def snapshot():
+        return ([[None if p.grad is None else p.grad.clone() for p in m.parameters()] for m in models],
+                [{k: v.clone() for k, v in m.state_dict().items()} for m in models])
+
+    def same(a, b):
+        (ga, sa), (gb, sb) = a, b
+        ok = all((p is None and q is None) or torch.equal(p, q) for x_, y_ in zip(ga, gb) for p, q in zip(x_, y_))
+        return ok and all(torch.equal(v, t[k]) for s, t in zip(sa, sb) for k, v in s.items())
+
+    ref_loss = step([None] * nm)
+    torch.cuda.synchronize()
+    ref = snapshot()
+    say(f'{mode}: one-stream reference done ({nm} models)')
+    sts = [torch.cuda.Stream(dev) for _ in range(nm)]
+    reset()
+    loss = step(sts)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(loss, ref_loss)) and same(snapshot(), ref), 'eager multi-stream step differs'
+    keys = [k for k in Fn._SIDE if k[0] == dev.index]
+    handles = [s.cuda_stream for k in keys for s in Fn._SIDE[k]]
+    assert len(handles) == len(set(handles)), 'a side stream serves two main streams'
+    say(f'{mode}: eager multi-stream step bit-identical; {len(keys)} side pools, {len(handles)} side streams')
+    if mode == 'eager':
+        return
+    reset()
+    g = torch.cuda.CUDAGraph()
+    kw = dict(capture_error_mode='relaxed') if mode == 'capture_relaxed' else {}
+    with torch.cuda.graph(g, **kw):
+        closs = step(sts)
+    say(f'{mode}: captured')
+    cgrads = [[p.grad for p in m.parameters()] for m in models]
+    for it in range(2):
+        reset()
+        g.replay()
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(closs, ref_loss)), 'captured losses differ'
+        if backward:
+            got = (cgrads, [{k: v for k, v in m.state_dict().items()} for m in models])
+            assert same(got, ref), 'captured step differs'
+        say(f'{mode}: replay {it} bit-identical')
+
+
+if __name__ == '__main__':
+    main()
+    say(f'{mode}: OK')
