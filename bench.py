@@ -327,9 +327,11 @@ def main():
     ap.add_argument('--batch', type=int, default=None, help='clips per GPU (per stream); default 256, 128 for --config 4stream')
     ap.add_argument('--config', choices=('ucla', '4stream'), default='ucla')
     ap.add_argument('--no-graph', action='store_true')
-    ap.add_argument('--fork-streams', type=int, default=None,
-                    help='4stream: 1 = every model on its own HIP stream (forward and, through autograd, backward), 0 = one after '
-                         'the other on one stream; default 1')
+    ap.add_argument('--fork-streams', type=int, default=0,
+                    help='4stream: number of HIP streams the four models are spread over (forward and, through autograd, backward): '
+                         '0 or 1 = one after the other on the current stream (default); 2 or 4 = that many at a time, with --no-graph '
+                         'only: eagerly the step is bit-identical to the one-stream step, replayed from a HIP graph one model\'s '
+                         'gradients come back 1e-4 off (profiles/r03_stream_capture_bisect.txt)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -401,8 +403,14 @@ def main():
         from tam_gcn_amd.functional import CrossEntropyLoss
         ce = CrossEntropyLoss()                             # the harness's nn.CrossEntropyLoss() as two HIP launches (row f1)
 
-        fork = four and (args.fork_streams is None or bool(args.fork_streams))
-        model_streams = [torch.cuda.Stream(dev) for _ in streams] if fork else []
+        nfork = args.fork_streams if four and args.fork_streams > 1 else 0
+        if nfork > 1 and not args.no_graph:
+            raise RuntimeError('bench.py: --fork-streams > 1 needs --no-graph: a HIP graph that holds several model branches side by '
+                               'side replays with one model\'s gradients ~1e-4 off on this stack, while the same streams are '
+                               'bit-identical eagerly (profiles/r03_stream_capture_bisect.txt)')
+        fork = nfork > 1
+        pool = [torch.cuda.Stream(dev) for _ in range(nfork)]
+        model_streams = [pool[i % nfork] for i in range(len(streams))] if fork else []     # models i, i + nfork, ... share a stream
 
         def fwd_bwd():
             bucket.zero()
@@ -411,13 +419,14 @@ def main():
             losses = []
             for i, (name, m) in enumerate(zip(streams, models)):   # the streams are derived on the GPU from the resident joint clips
                 ctx = contextlib.nullcontext()
-                if fork:                                  # the four models are independent until the bucket: one HIP stream each.
-                    model_streams[i].wait_stream(cur)     # Autograd replays every node on the stream of its forward and joins
+                if fork:                                  # the four models are independent until the bucket.
+                    if i < nfork:
+                        model_streams[i].wait_stream(cur)     # Autograd replays every node on the stream of its forward and joins
                     ctx = _Fm.model_stream(model_streams[i])     # the leaf streams into `cur` when backward() returns.
                 with ctx:
                     xs = x if name == 'joint' else _ops.stream_derive(x, parent, name)
                     losses.append(ce(m(xs), lab))
-            for st in model_streams:
+            for st in pool:
                 cur.wait_stream(st)
             for loss in losses:
                 total = loss if total is None else total + loss

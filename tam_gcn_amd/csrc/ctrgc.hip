@@ -9,20 +9,24 @@
 // ctrgc_fwd_kernel: one workgroup owns one sample n and a tile of CT output channels, for all S subsets and
 // all T frames:
 //   1. the E tiles of its channels (S*CT*V*V floats) are loaded into LDS and stay there;
-//   2. per chunk of BT frames, x3 = W3 x + b3 for the S*CT rows is an MFMA GEMM over an LDS-staged x tile:
-//      16-byte global loads (coalesced along t*V+v) are prefetched into registers one K chunk ahead, so
-//      HBM/L2 latency hides under the MFMAs; the result lands in an LDS tile [s*CT+c][t][v];
-//   3. the V-aggregation  z[c,t,u] = sum_s sum_v E_s[c,u,v]*x3_s[c,t,v]  runs on the VALU with a (TB frames x
-//      UB joints) register block per thread, E read as 16-byte LDS vectors;
+//   2. per chunk of BT = 16 frames, x3 = W3 x + b3 for the S*CT rows is an MFMA GEMM over an LDS-staged x tile:
+//      16-byte global loads (coalesced along t*V+v) are prefetched into registers one K chunk ahead -- across the
+//      chunk boundary too: the next chunk's first operands are requested before the copy-out stores of this one;
+//   3. the V-aggregation  z[c,t,u] = sum_s sum_v E_s[c,u,v]*x3_s[c,t,v]  is a per-channel (16 frames) x (V joints) x
+//      (K = S*V) product on the matrix cores: both operands are rows of K contiguous floats in LDS (the x3 tile is
+//      written as [c][frame][s*V+v], E as [c][u][s*V+v]) read as 16-byte vectors; rounds 1-2 ran it on the VALU with
+//      E rows as 16-byte LDS reads: 3.4 of the 10 k LDS clocks per chunk, and as many VALU cycles as the GEMM takes
+//      MFMA cycles (the fp32-input MFMA runs at the vector rate);
 //   4. z is staged through LDS and written as whole contiguous rows, the x3 tile is written out for the
 //      backward, and the train-mode BatchNorm moments of z are accumulated on the way (per-sample partials).
-// CT = 8: E tiles 38 KB + x3 tile 31 KB + z tile 10 KB = 78 KB, 256 threads: TWO workgroups share a CU, so
-// that one's matrix phase (2) runs beside the other's vector / copy phases (3, 4) -- the phases of one
-// workgroup are serial (barriers between them), and with 16-channel tiles (158 KB, one workgroup per CU)
-// nothing overlapped anything: 24 % matrix-pipe busy at C = 64 (profiles/r02f_pmc_ctrgc_64_64_T64.txt).
-// The x3 GEMM then has S*CT = 24 rows in two 16-row MFMA tiles (25 % padding).
+// Geometries.  Forward: CT = 16 channels, 512 threads, E 77 KB + x3 tile 61 KB + z tile 20 KB = 155 KB (one workgroup
+// per CU): the x3 GEMM has S*CT = 48 rows = three full 16-row MFMA tiles.  An 8-channel form (78 KB, 256 threads, two
+// workgroups per CU, 24 rows in two padded tiles) is kept for Cout % 16 == 8; it measured 8-17 % slower at every layer
+// shape: two workgroups of four waves put the same two waves on a SIMD as one workgroup of eight, and the phases that
+// bound the kernel -- waiting for the staged operands and for the copy-out stores to drain (vmcnt retires in order) --
+// do not overlap better for it.  dx3 (no GEMM, no staging): CT = 8, two workgroups per CU.
 //
-// ctrgc_bwd_dx3_kernel:  dx3_s[c,t,v] = sum_u E_s[c,u,v] dy[c,t,u]  (E^T tiles in LDS), same geometry.
+// ctrgc_bwd_dx3_kernel:  dx3_s[c,t,v] = sum_u E_s[c,u,v] dy[c,t,u], on the matrix cores from the same E layout.
 //
 // All MFMA blocks are branch-free with compile-time tile counts (padding tiles are computed
 // and discarded): per-MFMA guards made hipcc serialise every ds_read/MFMA pair.
@@ -81,11 +85,14 @@ __device__ __forceinline__ bool block_coords(const CtrgcArgs& a, int& n, int& c0
     return n < a.N;
 }
 
-// E tiles of channels c0..c0+CT-1 from the tensor tamgcn_ctrgc_build_e wrote, (N, S, Cout, V*V): per subset the
-// CT rows are one contiguous run, fetched with 16-byte loads in a single batch.  Es[s][c][u*V+v] (or [v*V+u]).
+// E tiles of channels c0..c0+CT-1 from the tensor tamgcn_ctrgc_build_e wrote, (N, S, Cout, V*V): per subset the CT rows
+// are one contiguous run, fetched with 16-byte loads in a single batch, into the layout of the MFMA aggregation:
+// Ek[c][u][s*V + v] (one row of KP = S*V floats per (channel, joint u)):
+// row u of a channel is the B operand's k axis, contiguous for 16-byte fragment reads; rows are 240 B apart at S = 3, V = 20,
+// i.e. 15 sixteen-byte slots: the sixteen rows a fragment read touches sit in sixteen different slots of the bank row.
 template <class G, int ST>
-__device__ __forceinline__ void load_E(const float* __restrict__ Eg, int Cout, int n, int c0, float* Es, bool transpose) {
-    constexpr int V = G::V, VV = G::VV, NT = G::NT, CT = G::CT;
+__device__ __forceinline__ void load_E_k(const float* __restrict__ Eg, int Cout, int n, int c0, float* Ek) {
+    constexpr int V = G::V, VV = G::VV, NT = G::NT, CT = G::CT, KP = ST * V;
     constexpr int PER = CT * VV / 4;                   // float4 per subset
     constexpr int NL = (ST * PER + NT - 1) / NT;
     float4 t[NL];
@@ -99,18 +106,9 @@ __device__ __forceinline__ void load_E(const float* __restrict__ Eg, int Cout, i
     for (int i = 0; i < NL; ++i) {
         const int e = threadIdx.x + i * NT;
         if (e < ST * PER) {
-            if (!transpose) {
-                reinterpret_cast<float4*>(Es)[e] = t[i];          // same linear order: [s][c][uv]
-            } else {
-                const float vals[4] = {t[i].x, t[i].y, t[i].z, t[i].w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int f = e * 4 + k;
-                    const int row = f / VV, uv = f - row * VV;   // row = s*CT + c
-                    const int u = uv / V, v = uv - u * V;
-                    Es[row * VV + v * V + u] = vals[k];
-                }
-            }
+            const int sidx = e / PER, r = e - sidx * PER;          // r: float4 index inside [c][u][v]
+            const int cu = (r * 4) / V, v = r * 4 - cu * V;        // cu = c*V + u
+            *reinterpret_cast<float4*>(Ek + cu * KP + sidx * V + v) = t[i];
         }
     }
     __syncthreads();
@@ -204,18 +202,85 @@ __global__ __launch_bounds__(512) void ctrgc_E_kernel(const EArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// x3 tile for frames [t0, t0+bt): X3[(s*CT+c)*PX3 + tl*V + v] = (W3_s x)[c0+c] + b3
-// The staging buffers alias the X3 tile (they are dead before the tile is written).
+// One K chunk (SBK input channels) of the x3 GEMM's operands on its way from global memory to the LDS stage: SBK rows of
+// the x tile and the matching weight columns, as registers.  load() issues the reads; pin() makes the compiler wait for
+// them at THAT point (vmcnt retires in order and counts stores: a wait placed after the copy-out stores of a chunk would
+// also wait for those stores to drain to HBM -- the loads of the next chunk are therefore issued before the stores and
+// pinned before the first store leaves).
 // ---------------------------------------------------------------------------
 template <class G, int ST>
-__device__ void x3_chunk(const CtrgcArgs& a, int n, int c0, int t0, int bt, float* X3) {
+struct X3Pref {
     using P = Plan<G, ST>;
-    constexpr int V = G::V, NT = G::NT, CW = G::CW, NPF = G::NPF, SBK = G::SBK, SBKP = G::SBKP, CT = G::CT;
+    static constexpr int NPF = G::NPF, NT = G::NT, SBK = G::SBK, CT = G::CT;
+    static constexpr int ROWV = G::NCOLS / 4;                     // vectors per row (full chunk geometry)
+    static constexpr int NAF = (P::NRT * 16 * SBK + NT - 1) / NT; // weight-tile values per thread
+    float4 rv[NPF];
+    float wv[NAF];
+
+    __device__ __forceinline__ void load(const CtrgcArgs& a, int n, int c0, int t0, int bt, int k0) {
+        constexpr int V = G::V;
+        const int tid = threadIdx.x, ncols = bt * V;
+        const long long cs = (long long)a.T * V;
+        const long long xb = ((long long)n * a.x_ctot + a.x_coff) * cs + (long long)t0 * V;
+#pragma unroll
+        for (int i = 0; i < NAF; ++i) {
+            const int e = tid + i * NT;
+            const int kk = e % SBK, row = e / SBK;
+            const int sidx = row / CT, c = row - sidx * CT, k = k0 + kk;
+            wv[i] = (row < P::NR && k < a.Cin) ? a.w3[((long long)sidx * a.Cout + c0 + c) * a.Cin + k] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int e = tid + i * NT;
+            const int kk = e / ROWV, pos = (e - kk * ROWV) * 4;
+            const int k = k0 + kk;
+            const bool ok = kk < SBK && k < a.Cin && pos < ncols;
+            rv[i] = ok ? *reinterpret_cast<const float4*>(a.x + xb + (long long)k * cs + pos) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __device__ __forceinline__ void pin() {
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) asm volatile("" : "+v"(rv[i].x), "+v"(rv[i].y), "+v"(rv[i].z), "+v"(rv[i].w));
+#pragma unroll
+        for (int i = 0; i < NAF; ++i) asm volatile("" : "+v"(wv[i]));
+    }
+    __device__ __forceinline__ void commit(float* As, float* Bs) const {    // registers -> LDS stage
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < NAF; ++i) {
+            const int e = tid + i * NT;
+            const int kk = e % SBK, row = e / SBK;
+            if (row < P::NRT * 16) As[row * G::SBKP + kk] = wv[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int e = tid + i * NT;
+            const int kk = e / ROWV, pos = (e - kk * ROWV) * 4;
+            if (kk < SBK) *reinterpret_cast<float4*>(Bs + kk * G::PITCHB + pos) = rv[i];
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------
+// x3 tile for frames [t0, t0+bt): X3[(s*CT+c)*PX3 + tl*V + v] = (W3_s x)[c0+c] + b3
+// The staging buffers alias the X3 tile (they are dead before the tile is written).  pf holds the first K chunk of THIS
+// frame chunk (loaded by the caller, or by the previous call); when a next frame chunk exists its first K chunk is
+// requested right after the K loop, so that it travels under the tile write, the aggregation and the copy-out.
+// ---------------------------------------------------------------------------
+template <class G, int ST>
+__device__ void x3_chunk(const CtrgcArgs& a, int n, int c0, int t0, int bt, float* X3, X3Pref<G, ST>& pf, int next_t0, int next_bt) {
+    // the tile leaves as X3[(c*BT + frame)*KP + s*V + v], KP = S*V: a (channel, frame) row holds the aggregation's k axis
+    using P = Plan<G, ST>;
+    constexpr int V = G::V, CW = G::CW, SBK = G::SBK, SBKP = G::SBKP, CT = G::CT;
     constexpr int NR = P::NR, NRT = P::NRT, PB = G::PITCHB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kq = lane >> 4;
     const int ncols = bt * V;
-    const int cw0 = wave * CW;
+    // Column tiles per wave.  Waves w and w + 4 share a SIMD (its MFMA pipe): with 20 tiles on 8 waves, "3 per wave in
+    // order" would load the four SIMDs 6/6/5/3; every SIMD gets 5 instead -- wave w < 4 takes three, wave w + 4 two.
+    constexpr bool BAL = (G::NW == 8 && G::NCT == 20);
+    const int cw0 = BAL ? 5 * (wave & 3) + (wave < 4 ? 0 : 3) : wave * CW;
+    const bool third = !BAL || wave < 4;               // wave-uniform: does tile c = 2 exist for this wave
     float* Bs = X3;                                   // [SBK][PB]
     float* As = X3 + SBK * PB;                        // [NRT*16][SBKP]
 
@@ -226,38 +291,8 @@ __device__ void x3_chunk(const CtrgcArgs& a, int n, int c0, int t0, int bt, floa
         for (int c = 0; c < CW; ++c) acc[rt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
     int bcol[CW];
 #pragma unroll
-    for (int c = 0; c < CW; ++c) { int col = (cw0 + c) * 16 + j; bcol[c] = col < ncols ? col : 0; }
+    for (int c = 0; c < CW; ++c) { int col = (cw0 + c) * 16 + j; bcol[c] = (col < ncols && (c < 2 || third)) ? col : 0; }
 
-    const long long cs = (long long)a.T * V;
-    const long long xb = ((long long)n * a.x_ctot + a.x_coff) * cs + (long long)t0 * V;
-    // prefetch descriptors: element e -> (row kk, position pos) of the [SBK][NCOLS] chunk
-    int p_kk[NPF], p_pos[NPF];
-    constexpr int ROWV = G::NCOLS / 4;                // vectors per row (full chunk geometry)
-#pragma unroll
-    for (int i = 0; i < NPF; ++i) {
-        int e = tid + i * NT;
-        int kk = e / ROWV, pv = e - kk * ROWV;
-        p_kk[i] = kk < SBK ? kk : -1;
-        p_pos[i] = pv * 4;
-    }
-    float4 rv[NPF];
-    constexpr int NAF = (NRT * 16 * SBK + NT - 1) / NT;           // weight-tile values per thread
-    float wv[NAF];
-    auto prefetch = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < NAF; ++i) {
-            int e = tid + i * NT;
-            int kk = e % SBK, row = e / SBK;
-            int sidx = row / CT, c = row - sidx * CT, k = k0 + kk;
-            wv[i] = (row < NR && k < a.Cin) ? a.w3[((long long)sidx * a.Cout + c0 + c) * a.Cin + k] : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < NPF; ++i) {
-            const int k = k0 + p_kk[i];
-            const bool ok = p_kk[i] >= 0 && k < a.Cin && p_pos[i] < ncols;
-            rv[i] = ok ? *reinterpret_cast<const float4*>(a.x + xb + (long long)k * cs + p_pos[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
     float b3r[NRT][4];                                 // fetched here: in flight under the K loop, not exposed after it
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt)
@@ -267,20 +302,12 @@ __device__ void x3_chunk(const CtrgcArgs& a, int n, int c0, int t0, int bt, floa
             const int sidx = row / CT, c = row - sidx * CT;
             b3r[rt][r] = row < NR ? a.b3[sidx * a.Cout + c0 + c] : 0.f;
         }
-    prefetch(0);
     for (int k0 = 0; k0 < a.Cin; k0 += SBK) {
         __syncthreads();                               // previous users of the region are done
-#pragma unroll
-        for (int i = 0; i < NAF; ++i) {
-            int e = tid + i * NT;
-            int kk = e % SBK, row = e / SBK;
-            if (row < NRT * 16) As[row * SBKP + kk] = wv[i];
-        }
-#pragma unroll
-        for (int i = 0; i < NPF; ++i)
-            if (p_kk[i] >= 0) *reinterpret_cast<float4*>(Bs + p_kk[i] * PB + p_pos[i]) = rv[i];
+        pf.commit(As, Bs);
         __syncthreads();
-        if (k0 + SBK < a.Cin) prefetch(k0 + SBK);      // in flight under the MFMAs
+        if (k0 + SBK < a.Cin) pf.load(a, n, c0, t0, bt, k0 + SBK);      // in flight under the MFMAs
+        else if (next_bt > 0) pf.load(a, n, c0, next_t0, next_bt, 0);   // the next frame chunk's first K chunk
         const float* at = As + j * SBKP + kq;
         const float* bt_ = Bs + kq * PB;
 #pragma unroll
@@ -291,9 +318,13 @@ __device__ void x3_chunk(const CtrgcArgs& a, int n, int c0, int t0, int bt, floa
 #pragma unroll
             for (int c = 0; c < CW; ++c) bv[c] = bt_[k4 * 4 * PB + bcol[c]];
 #pragma unroll
-            for (int c = 0; c < CW; ++c)
+            for (int c = 0; c < (BAL ? 2 : CW); ++c)
 #pragma unroll
                 for (int rt = 0; rt < NRT; ++rt) acc[rt][c] = mfma16(av[rt], bv[c], acc[rt][c]);
+            if (BAL && third) {                         // wave-uniform branch around the third tile's MFMAs
+#pragma unroll
+                for (int rt = 0; rt < NRT; ++rt) acc[rt][2] = mfma16(av[rt], bv[2], acc[rt][2]);
+            }
         }
     }
     __syncthreads();                                   // stage dead; X3 may be overwritten
@@ -302,44 +333,68 @@ __device__ void x3_chunk(const CtrgcArgs& a, int n, int c0, int t0, int bt, floa
 #pragma unroll
         for (int c = 0; c < CW; ++c) {
             int col = (cw0 + c) * 16 + j;
-            if (col >= ncols) continue;
+            if (col >= ncols || (BAL && c == 2 && !third)) continue;
+            const int fr = col / V, v = col - fr * V;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = rt * 16 + kq * 4 + r;
-                if (row < NR) X3[row * G::PX3 + col] = acc[rt][c][r] + b3r[rt][r];
+                const int sidx = row / CT, ch = row - sidx * CT;
+                if (row < NR) X3[(ch * G::BT + fr) * (ST * V) + sidx * V + v] = acc[rt][c][r] + b3r[rt][r];
             }
         }
     }
     __syncthreads();
 }
 
-// out[tt][ub] (+)= sum_b M[a0+ub][b] * in[tt*V + b]
-template <int V, int TB>
-__device__ __forceinline__ void aggregate(const float* Mc, const float* inrow, int a0, float (&out)[TB][(V + 3) / 4]) {
-    constexpr int UB = (V + 3) / 4;
-    float xin[TB][V];
+// ---------------------------------------------------------------------------
+// V-aggregation on the matrix cores:  z[c][t][u] = sum_k x3[c][t][k] * E[c][u][k],  k = (s, v), K = S*V (60, padded to 64).
+// Per channel a (16 frames) x (V joints, two 16-column tiles) x K product; lane (i, kq) reads its operands as 16-byte
+// vectors: k = 16*m + 4*kq + r is element r of vector m -- any assignment of k to (step, lane) is valid as long as both
+// operands use the same one.  The four k beyond K (m = 3, kq = 3 at K = 60) are zeroed in BOTH operands (what lies
+// behind a row is the next row, or stale bytes behind the tile).  Wave w owns channels w, w + NW, ...; the two column
+// tiles of a channel share its A fragments and alternate, so consecutive MFMAs never wait on each other's accumulator.
+// ---------------------------------------------------------------------------
+template <class G, int ST>
+__device__ __forceinline__ void aggregate_mfma(const float* Ek, const float* X3, float* Zs, int bt) {
+    constexpr int V = G::V, CT = G::CT, KP = ST * V, NM = (KP + 15) / 16, NUT = (V + 15) / 16;
+    static_assert(G::BT == 16, "one 16-frame MFMA row tile per chunk");
+    static_assert(KP % 4 == 0, "rows are read as 16-byte vectors");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    for (int c = wave; c < CT; c += G::NW) {
+        f32x4 av[NM], bv[NUT][NM];
 #pragma unroll
-    for (int tt = 0; tt < TB; ++tt) {
+        for (int m = 0; m < NM; ++m) {
+            const bool in = 16 * m + 4 * kq < KP;                 // whole vector inside the row (KP % 4 == 0)
+            const int ko = in ? 16 * m + 4 * kq : 0;
+            av[m] = *reinterpret_cast<const f32x4*>(X3 + (c * G::BT + j) * KP + ko);
 #pragma unroll
-        for (int b = 0; b < V; b += 4) {
-            f32x4 t = *reinterpret_cast<const f32x4*>(inrow + tt * V + b);
-            xin[tt][b] = t[0]; xin[tt][b + 1] = t[1]; xin[tt][b + 2] = t[2]; xin[tt][b + 3] = t[3];
+            for (int ut = 0; ut < NUT; ++ut) {
+                const int u = ut * 16 + j < V ? ut * 16 + j : V - 1;   // padding columns repeat the last joint: discarded below
+                bv[ut][m] = *reinterpret_cast<const f32x4*>(Ek + (c * V + u) * KP + ko);
+            }
+            if (!in) {
+                av[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ut = 0; ut < NUT; ++ut) bv[ut][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
         }
-    }
+        f32x4 acc[NUT];
 #pragma unroll
-    for (int ub = 0; ub < UB; ++ub) {
-        int aidx = a0 + ub;
-        if (aidx >= V) break;
-        const float* mrow = Mc + aidx * V;
+        for (int ut = 0; ut < NUT; ++ut) acc[ut] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int b = 0; b < V; b += 4) {
-            f32x4 m = *reinterpret_cast<const f32x4*>(mrow + b);
+        for (int m = 0; m < NM; ++m)
 #pragma unroll
-            for (int tt = 0; tt < TB; ++tt) {
-                out[tt][ub] = fmaf(m[0], xin[tt][b], out[tt][ub]);
-                out[tt][ub] = fmaf(m[1], xin[tt][b + 1], out[tt][ub]);
-                out[tt][ub] = fmaf(m[2], xin[tt][b + 2], out[tt][ub]);
-                out[tt][ub] = fmaf(m[3], xin[tt][b + 3], out[tt][ub]);
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int ut = 0; ut < NUT; ++ut) acc[ut] = mfma16(av[m][r], bv[ut][m][r], acc[ut]);
+#pragma unroll
+        for (int ut = 0; ut < NUT; ++ut) {
+            const int u = ut * 16 + j;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int fr = kq * 4 + r;
+                if (u < V && fr < bt) Zs[c * G::NCOLS + fr * V + u] = acc[ut][r];
             }
         }
     }
@@ -373,6 +428,14 @@ struct DyTile {
             v2[i][0] = b4.x; v2[i][1] = b4.y; v2[i][2] = b4.z; v2[i][3] = b4.w;
         }
     }
+    __device__ __forceinline__ void pin() {             // make the compiler wait for the loads HERE (see X3Pref)
+#pragma unroll
+        for (int i = 0; i < NDY; ++i) {
+            asm volatile("" : "+v"(v1[i][0]), "+v"(v1[i][1]), "+v"(v1[i][2]), "+v"(v1[i][3]));
+            asm volatile("" : "+v"(v2[i][0]), "+v"(v2[i][1]), "+v"(v2[i][2]), "+v"(v2[i][3]));
+            asm volatile("" : "+v"(c1[i]), "+v"(c2[i]), "+v"(c0[i]));
+        }
+    }
     __device__ __forceinline__ void commit(const SrcDev& dy, float* Zs) {
 #pragma unroll
         for (int i = 0; i < NDY; ++i) {
@@ -397,49 +460,32 @@ struct DyTile {
 template <class G, int ST>
 __global__ __launch_bounds__(G::NT, 2) void ctrgc_fwd_kernel(const CtrgcArgs a, float* y, float* stats_part, float* x3_out) {
     using P = Plan<G, ST>;
-    constexpr int V = G::V, TB = G::TB, CT = G::CT;
+    constexpr int V = G::V, CT = G::CT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int n, c0;
     if (!block_coords<G>(a, n, c0)) return;
-    float* Es = smem;                                  // [S][CT][VV]
-    float* X3 = Es + P::NR * G::VV;                    // REGION floats
+    float* Es = smem;                                  // [CT][V][S*V]: row (c, u) = E_s[c][u][v] over (s, v)
+    float* X3 = Es + P::NR * G::VV;                    // REGION floats: GEMM stage, then the x3 tile [CT][BT][S*V]
     float* Zs = X3 + P::REGION;                        // [CT][NCOLS]
     const int tid = threadIdx.x;
-    const int c = tid / (G::NTQ * 4), tq = (tid >> 2) % G::NTQ, uq = tid & 3;
+    const int c = tid / (G::NTQ * 4);
     const int lrow = tid % (G::NTQ * 4);               // lane index inside the channel row (copy-out)
 
     TG_T(tt0);
-    load_E<G, ST>(a.E, a.Cout, n, c0, Es, false);
+    X3Pref<G, ST> pf;
+    pf.load(a, n, c0, 0, min(G::BT, a.T), 0);          // first operands of the first chunk: in flight under the E load
+    load_E_k<G, ST>(a.E, a.Cout, n, c0, Es);
     TG_T(tt1); TG_ACC(0, tt1 - tt0);
 
     float st1 = 0.f, st2 = 0.f;
     for (int t0 = 0; t0 < a.T; t0 += G::BT) {
         const int bt = min(G::BT, a.T - t0);
         const int ncols = bt * V;
+        const int nt0 = t0 + G::BT, nbt = nt0 < a.T ? min(G::BT, a.T - nt0) : 0;
         TG_T(ta);
-        x3_chunk<G, ST>(a, n, c0, t0, bt, X3);
+        x3_chunk<G, ST>(a, n, c0, t0, bt, X3, pf, nt0, nbt);
         TG_T(tb); TG_ACC(1, tb - ta);
-        float z[TB][G::UB];
-#pragma unroll
-        for (int tt = 0; tt < TB; ++tt)
-#pragma unroll
-            for (int ub = 0; ub < G::UB; ++ub) z[tt][ub] = 0.f;
-        if (tq * TB < bt) {       // rows beyond bt hold stale data: results are discarded below
-#pragma unroll
-            for (int s = 0; s < ST; ++s)
-                aggregate<V, TB>(Es + (s * CT + c) * G::VV, X3 + (s * CT + c) * G::PX3 + tq * TB * V, uq * G::UB, z);
-        }
-#pragma unroll
-        for (int tt = 0; tt < TB; ++tt) {
-            int tl = tq * TB + tt;
-            if (tl < bt) {
-#pragma unroll
-                for (int ub = 0; ub < G::UB; ++ub) {
-                    int u = uq * G::UB + ub;
-                    if (u < V) Zs[c * G::NCOLS + tl * V + u] = z[tt][ub];
-                }
-            }
-        }
+        aggregate_mfma<G, ST>(Es, X3, Zs, bt);      // frames beyond bt hold stale data: their rows are not stored
         TG_T(tc); TG_ACC(2, tc - tb);
         __syncthreads();
         TG_T(td); TG_ACC(3, td - tc);
@@ -454,14 +500,17 @@ __global__ __launch_bounds__(G::NT, 2) void ctrgc_fwd_kernel(const CtrgcArgs a, 
             const int p4 = lrow + i * RL;
             zv[i] = p4 < (ncols >> 2) ? reinterpret_cast<const float4*>(Zs + c * G::NCOLS)[p4] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        if (nbt > 0) pf.pin();    // the next chunk's operands have landed: no load is left in front of the stores below
         if (x3_out) {             // keep x3 for the backward (saves recomputing the GEMM there)
             float4 xv[ST][NV4];
 #pragma unroll
             for (int s = 0; s < ST; ++s)
 #pragma unroll
                 for (int i = 0; i < NV4; ++i) {
-                    const int p4 = lrow + i * RL;
-                    xv[s][i] = p4 < (ncols >> 2) ? reinterpret_cast<const float4*>(X3 + (s * CT + c) * G::PX3)[p4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const int p4 = lrow + i * RL;                  // float4 p4 of the output row = (frame p4 / (V/4), joints 4*(p4 % (V/4)) ..)
+                    const int fr = p4 / (V / 4), q = p4 - fr * (V / 4);
+                    xv[s][i] = p4 < (ncols >> 2) ? *reinterpret_cast<const float4*>(X3 + (c * G::BT + fr) * (ST * V) + s * V + 4 * q)
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
             for (int s = 0; s < ST; ++s) {
@@ -498,29 +547,69 @@ __global__ __launch_bounds__(G::NT, 2) void ctrgc_fwd_kernel(const CtrgcArgs a, 
 }
 
 // ---------------------------------------------------------------------------
-// backward: dx3
+// backward: dx3_s[c][t][v] = sum_u dy[c][t][u] * E_s[c][u][v]  -- per channel a (16 frames) x (S*V columns) x (V joints)
+// product on the matrix cores: A = the dy tile row (c, frame), k = u; B = the E rows of the forward's layout
+// Ek[c][u][s*V + v] read along (s, v); k = 4*ks + kq.  Wave w owns channels w, w + NW, ...
 // ---------------------------------------------------------------------------
+template <class G, int ST>
+__device__ __forceinline__ void dx3_mfma(const float* Ek, const float* Zs, float* X3, int bt) {
+    constexpr int V = G::V, CT = G::CT, KP = ST * V, NKS = (V + 3) / 4, NCT = (KP + 15) / 16;
+    static_assert(G::BT == 16, "one 16-frame MFMA row tile per chunk");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    for (int c = wave; c < CT; c += G::NW) {
+        float av[NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int u = 4 * ks + kq;
+            av[ks] = u < V ? Zs[c * G::NCOLS + j * V + u] : 0.f;
+        }
+        f32x4 acc[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int u = 4 * ks + kq < V ? 4 * ks + kq : V - 1;      // rows beyond V meet a zero A value
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const int col = ct * 16 + j < KP ? ct * 16 + j : KP - 1;   // padding columns: discarded below
+                acc[ct] = mfma16(av[ks], Ek[(c * V + u) * KP + col], acc[ct]);
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const int col = ct * 16 + j;
+            const int sidx = col / V, v = col - sidx * V;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int fr = kq * 4 + r;
+                if (col < KP && fr < bt) X3[(sidx * CT + c) * G::PX3 + fr * V + v] = acc[ct][r];
+            }
+        }
+    }
+}
+
 template <class G, int ST>
 __global__ __launch_bounds__(G::NT, 2) void ctrgc_bwd_dx3_kernel(const CtrgcArgs a, const SrcDev dy, float* dx3, float* db3_part) {
     using P = Plan<G, ST>;
-    constexpr int V = G::V, TB = G::TB, CT = G::CT;
+    constexpr int V = G::V, CT = G::CT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int n, c0;
     if (!block_coords<G>(a, n, c0)) return;
-    float* Es = smem;                                  // transposed tiles [S][CT][v][u]
+    float* Es = smem;                                  // [CT][V][S*V], the forward's layout
     float* X3 = Es + P::NR * G::VV;                    // output staging [S*CT][PX3]
     float* Zs = X3 + P::REGION;                        // dy chunk [CT][NCOLS]
     const int tid = threadIdx.x;
-    const int c = tid / (G::NTQ * 4), tq = (tid >> 2) % G::NTQ, vq = tid & 3;
+    const int c = tid / (G::NTQ * 4);
     const int lrow = tid % (G::NTQ * 4);
 
-    load_E<G, ST>(a.E, a.Cout, n, c0, Es, true);
+    DyTile<G> dyt;
+    dyt.load(dy, n, c0, a.T, 0, min(G::BT, a.T));      // in flight under the E load
+    load_E_k<G, ST>(a.E, a.Cout, n, c0, Es);
 
     float sb[ST];
 #pragma unroll
     for (int s = 0; s < ST; ++s) sb[s] = 0.f;
-    DyTile<G> dyt;
-    dyt.load(dy, n, c0, a.T, 0, min(G::BT, a.T));
     for (int t0 = 0; t0 < a.T; t0 += G::BT) {
         const int bt = min(G::BT, a.T - t0);
         const int ncols = bt * V;
@@ -528,29 +617,9 @@ __global__ __launch_bounds__(G::NT, 2) void ctrgc_bwd_dx3_kernel(const CtrgcArgs
         dyt.commit(dy, Zs);
         __syncthreads();
         if (t0 + G::BT < a.T) dyt.load(dy, n, c0, a.T, t0 + G::BT, min(G::BT, a.T - t0 - G::BT));   // next chunk in flight
-        if (tq * TB < bt) {
-#pragma unroll
-            for (int s = 0; s < ST; ++s) {
-                float o[TB][G::UB];
-#pragma unroll
-                for (int tt = 0; tt < TB; ++tt)
-#pragma unroll
-                    for (int ub = 0; ub < G::UB; ++ub) o[tt][ub] = 0.f;
-                aggregate<V, TB>(Es + (s * CT + c) * G::VV, Zs + c * G::NCOLS + tq * TB * V, vq * G::UB, o);
-#pragma unroll
-                for (int tt = 0; tt < TB; ++tt) {
-                    int tl = tq * TB + tt;
-                    if (tl < bt) {
-#pragma unroll
-                        for (int ub = 0; ub < G::UB; ++ub) {
-                            int v = vq * G::UB + ub;
-                            if (v < V) { X3[(s * CT + c) * G::PX3 + tl * V + v] = o[tt][ub]; sb[s] += o[tt][ub]; }
-                        }
-                    }
-                }
-            }
-        }
+        dx3_mfma<G, ST>(Es, Zs, X3, bt);
         __syncthreads();
+        if (t0 + G::BT < a.T) dyt.pin();               // the next dy chunk has landed before the first store below leaves
         constexpr int RL = G::NTQ * 4;
         constexpr int NV4 = (G::NCOLS / 4 + RL - 1) / RL;
         float4 xv[ST][NV4];
@@ -567,7 +636,10 @@ __global__ __launch_bounds__(G::NT, 2) void ctrgc_bwd_dx3_kernel(const CtrgcArgs
 #pragma unroll
             for (int i = 0; i < NV4; ++i) {
                 const int p4 = lrow + i * RL;
-                if (p4 < (ncols >> 2)) reinterpret_cast<float4*>(orow)[p4] = xv[s][i];
+                if (p4 < (ncols >> 2)) {
+                    reinterpret_cast<float4*>(orow)[p4] = xv[s][i];
+                    sb[s] += (xv[s][i].x + xv[s][i].y) + (xv[s][i].z + xv[s][i].w);
+                }
             }
         }
     }
@@ -586,14 +658,15 @@ __global__ __launch_bounds__(G::NT, 2) void ctrgc_bwd_dx3_kernel(const CtrgcArgs
 // host
 // ---------------------------------------------------------------------------
 using G20 = Geo<20, 8, 2, 8, 16>;      // 8 channels x 16 frames per chunk, 256 threads, 78 KB: two workgroups per CU
+using G20W = Geo<20, 16, 2, 8, 32>;    // 16 channels, 512 threads, 155 KB: one workgroup per CU, 48 GEMM rows = three full MFMA row tiles
 
-static int fill_args(const tamgcn_ctrgc_desc* d, CtrgcArgs* a, const char* who) {
+static int fill_args(const tamgcn_ctrgc_desc* d, CtrgcArgs* a, const char* who, int ct) {
     if (!(d->N > 0 && d->Cin > 0 && d->Cout > 0 && d->T > 0)) { tamgcn_set_error("%s: bad dims", who); return -1; }
     if (d->V != 20 || (d->S != 1 && d->S != 3)) {
         tamgcn_set_error("%s: unsupported S=%d V=%d (the LDS-resident kernels exist for S in {1,3}, V = 20; V in {25, 32, 64}: tamgcn_ctrgc_tiled_*)", who, d->S, d->V);
         return -1;
     }
-    if (d->Cout % G20::CT) { tamgcn_set_error("%s: Cout=%d must be a multiple of %d", who, d->Cout, G20::CT); return -1; }
+    if (d->Cout % ct) { tamgcn_set_error("%s: Cout=%d must be a multiple of %d", who, d->Cout, ct); return -1; }
     if (!(d->x.x1 && d->w3 && d->b3)) { tamgcn_set_error("%s: null pointer", who); return -1; }
     if (!d->E) { tamgcn_set_error("%s: d->E is NULL (build it with tamgcn_ctrgc_build_e)", who); return -1; }
     if (d->x.x2 || d->x.coef || d->x.act) { tamgcn_set_error("%s: x must be a plain tensor (no fused prologue)", who); return -1; }
@@ -604,25 +677,30 @@ static int fill_args(const tamgcn_ctrgc_desc* d, CtrgcArgs* a, const char* who) 
     a->N = d->N; a->Cin = d->Cin; a->Cout = d->Cout; a->S = d->S; a->T = d->T;
     a->x = d->x.x1; a->x_ctot = d->x.ctot; a->x_coff = d->x.coff;
     a->w3 = d->w3; a->b3 = d->b3; a->E = d->E;
-    a->nct = d->Cout / G20::CT;
+    a->nct = d->Cout / ct;
     return 0;
 }
 
 static unsigned grid_blocks(const CtrgcArgs& a) { return 8u * (unsigned)ceil_div(a.N, 8) * (unsigned)a.nct; }
 
-#define CTRGC_LAUNCH(KERNEL, ST_, FLAG, ...)                                                                    \
+#define CTRGC_LAUNCH(KERNEL, GEO, ST_, FLAG, ...)                                                               \
     do {                                                                                                        \
         static tg_devmask FLAG = 0;                                                                             \
-        constexpr size_t lds_ = Plan<G20, ST_>::LDS;                                                            \
-        tg_allow_lds((const void*)KERNEL<G20, ST_>, lds_, &FLAG);   /* exact size */                            \
+        constexpr size_t lds_ = Plan<GEO, ST_>::LDS;                                                            \
+        tg_allow_lds((const void*)KERNEL<GEO, ST_>, lds_, &FLAG);   /* exact size */                            \
         if (getenv("TAMGCN_DEBUG_OCC")) {                                                                       \
             int nb_ = -1;                                                                                       \
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_, (const void*)KERNEL<G20, ST_>, G20::NT, lds_); \
-            fprintf(stderr, "[tamgcn] %s<%d>: %d workgroups per CU (%zu B LDS, %d threads)\n", #KERNEL, ST_, nb_, lds_, G20::NT); \
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_, (const void*)KERNEL<GEO, ST_>, GEO::NT, lds_); \
+            fprintf(stderr, "[tamgcn] %s<CT %d, %d>: %d workgroups per CU (%zu B LDS, %d threads)\n", #KERNEL, GEO::CT, ST_, nb_, lds_, GEO::NT); \
         }                                                                                                       \
-        hipLaunchKernelGGL((KERNEL<G20, ST_>), dim3(grid_blocks(a)), dim3(G20::NT), lds_, (hipStream_t)stream, __VA_ARGS__); \
-        tamgcn_note_kernel(#KERNEL "<Geo<%d, %d, %d, %d, %d>, %d>", G20::V, G20::CT, G20::TB, G20::NTQ, G20::SBK, ST_); \
+        hipLaunchKernelGGL((KERNEL<GEO, ST_>), dim3(grid_blocks(a)), dim3(GEO::NT), lds_, (hipStream_t)stream, __VA_ARGS__); \
+        tamgcn_note_kernel(#KERNEL "<Geo<%d, %d, %d, %d, %d>, %d>", GEO::V, GEO::CT, GEO::TB, GEO::NTQ, GEO::SBK, ST_); \
     } while (0)
+
+// The forward's channel tile: 16 (48 GEMM rows = three full MFMA row tiles, x read by half as many workgroups) wherever
+// Cout allows; measured on one box against the 8-channel form (two workgroups per CU, 24 rows in two padded tiles):
+// 216 / 429 / 317 / 627 / 521 us against 243 / 462 / 357 / 696 / 608 us at the five layer shapes (profiles/r03_ctrgc_ab.txt).
+static int fwd_ct(int Cout) { return Cout % 16 ? 8 : 16; }
 
 }  // namespace
 
@@ -630,7 +708,7 @@ int tamgcn_ctrgc_tiled_lds_bytes(int S, int V, int R);      // ctrgc_tiled.hip: 
 
 extern "C" int tamgcn_ctrgc_lds_bytes(int S, int V, int R) {
     if (S != 1 && S != 3) return -1;
-    if (V == 20) return S == 3 ? (int)Plan<G20, 3>::LDS : (int)Plan<G20, 1>::LDS;     // the fused forward / dx3 workgroup
+    if (V == 20) return S == 3 ? (int)Plan<G20W, 3>::LDS : (int)Plan<G20W, 1>::LDS;   // the fused forward's workgroup (the largest)
     if (V == 25) {                                      // streaming route: the E builder is its largest request
         if (R < 4 || R > 32 || R % 4) return -1;
         return (int)(sizeof(float) * ((size_t)(16 + R) * V * V + 2 * (size_t)R * V));
@@ -664,9 +742,15 @@ extern "C" int tamgcn_ctrgc_build_e(const tamgcn_ctrgc_desc* d, float* E, void* 
 extern "C" int tamgcn_ctrgc_fwd(const tamgcn_ctrgc_desc* d, float* y, float* stats_part, float* x3_out, void* stream) {
     TG_CHECK(d && y, "tamgcn_ctrgc_fwd: null pointer");
     CtrgcArgs a;
-    if (fill_args(d, &a, "tamgcn_ctrgc_fwd")) return -1;
-    if (d->S == 3) CTRGC_LAUNCH(ctrgc_fwd_kernel, 3, f3, a, y, stats_part, x3_out);
-    else CTRGC_LAUNCH(ctrgc_fwd_kernel, 1, f1, a, y, stats_part, x3_out);
+    const int ct = fwd_ct(d->Cout);
+    if (fill_args(d, &a, "tamgcn_ctrgc_fwd", ct)) return -1;
+    if (ct == 16) {
+        if (d->S == 3) CTRGC_LAUNCH(ctrgc_fwd_kernel, G20W, 3, fw3, a, y, stats_part, x3_out);
+        else CTRGC_LAUNCH(ctrgc_fwd_kernel, G20W, 1, fw1, a, y, stats_part, x3_out);
+    } else {
+        if (d->S == 3) CTRGC_LAUNCH(ctrgc_fwd_kernel, G20, 3, f3, a, y, stats_part, x3_out);
+        else CTRGC_LAUNCH(ctrgc_fwd_kernel, G20, 1, f1, a, y, stats_part, x3_out);
+    }
     TG_LAUNCH_CHECK("tamgcn_ctrgc_fwd");
     return 0;
 }
@@ -678,9 +762,9 @@ extern "C" int tamgcn_ctrgc_bwd_dx3(const tamgcn_ctrgc_desc* d, const tamgcn_src
     tamgcn_ctrgc_desc dd = *d;                           // x, w3, b3 are not read by this kernel: only their presence is checked
     if (!dd.w3) dd.w3 = (const float*)d->E;
     if (!dd.b3) dd.b3 = (const float*)d->E;
-    if (fill_args(&dd, &a, "tamgcn_ctrgc_bwd_dx3")) return -1;
-    if (d->S == 3) CTRGC_LAUNCH(ctrgc_bwd_dx3_kernel, 3, f3, a, make_src(*dy), dx3, db3_part);
-    else CTRGC_LAUNCH(ctrgc_bwd_dx3_kernel, 1, f1, a, make_src(*dy), dx3, db3_part);
+    if (fill_args(&dd, &a, "tamgcn_ctrgc_bwd_dx3", G20::CT)) return -1;
+    if (d->S == 3) CTRGC_LAUNCH(ctrgc_bwd_dx3_kernel, G20, 3, f3, a, make_src(*dy), dx3, db3_part);
+    else CTRGC_LAUNCH(ctrgc_bwd_dx3_kernel, G20, 1, f1, a, make_src(*dy), dx3, db3_part);
     TG_LAUNCH_CHECK("tamgcn_ctrgc_bwd_dx3");
     return 0;
 }

@@ -1029,6 +1029,39 @@ class StGcnFn(_Fn):
         return (None, None, dx, dAe, dw3.reshape(a['K'] * Cout, Cin, 1, 1), db3, dg1, dbe1, dwt, dbt, dg2, dbe2, *gres)
 
 
+class TemporalConvFn(_Fn):
+    """Plain k x 1 convolution with bias over (N, C, T, V): stride, dilation and zero padding along T
+    (nn.Conv2d(C, M, (k, 1), (s, 1), (p, 0), (d, 1)); the graph convolution of models/stgcn.py:45-55 in its general form)."""
+
+    @staticmethod
+    def forward(ctx, cfg, x, w, b):
+        k, s, d, pad = cfg
+        x = x.contiguous()
+        y, _ = ops.conv(S(x), K=x.shape[1], w=w, bias=b, M=w.shape[0], KT=k, dil=d, stride=s, pad=pad)
+        ctx.cfg = cfg
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        k, s, d, pad = ctx.cfg
+        dy = dy.contiguous()
+        M, K, T = w.shape[0], x.shape[1], x.shape[2]
+        dw = ops.wgrad(S(dy), S(x), M=M, K=K, KT=k, dil=d, stride=s, pad=pad).reshape(w.shape)
+        db = dy.sum((0, 2, 3))
+        dx = None
+        if ctx.needs_input_grad[1]:
+            if k == 1:
+                dx = ops.zeros_like(x) if (s > 1 or pad > 0) else ops.empty_like(x)
+                if pad > 0:
+                    raise RuntimeError('tam_gcn_amd: a 1 x 1 convolution with temporal padding is not built')
+                ops.conv(S(dy), K=M, w=w.reshape(M, K), bias=None, M=K, wmode=1, y=dx, T_out=dy.shape[2], ostride=s)
+            else:
+                dx, _ = ops.conv(S(dy), K=M, w=w, bias=None, M=K, KT=k, dil=d, stride=1, pad=(k - 1) * d - pad, wmode=1, up=s, T_out=T)
+        return None, dx, dw, db
+
+
 class PointwiseConvFn(_Fn):
     """1x1 convolution with bias over (N, C, T, V) (ST-GCN's `fcn` applied per position in extract_feature, stgcn.py:218-219)."""
 

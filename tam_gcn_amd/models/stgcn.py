@@ -26,16 +26,27 @@ def bn_init(bn, scale):
 
 
 class ConvTemporalGraphical(nn.Module):
-    """Parameter container of the spatial graph convolution (reference :37-64); computed inside st_gcn's fused node.  Only the
-    1 x 1 form the model builds (t_kernel_size = 1) exists on the HIP path."""
+    """The spatial graph convolution (reference :37-64).  Inside st_gcn (the 1 x 1 form, the only one the model builds) it
+    is a parameter container: the block's fused node computes it on the CTRGC kernels.  Called on its own -- any
+    t_kernel_size / t_stride / t_padding / t_dilation, with or without bias -- the convolution runs on the k x 1 HIP
+    kernels and the joint contraction einsum('nkctv,kvw->nctw') as the library batched GEMM it is (a plain GEMM with a
+    shared (K*V) x V right-hand side: nothing to fuse with, and not on any configuration's path)."""
 
     def __init__(self, in_channels, out_channels, kernel_size, t_kernel_size=1, t_stride=1, t_padding=0, t_dilation=1, bias=True):
         super().__init__()
-        if (t_kernel_size, t_stride, t_padding, t_dilation) != (1, 1, 0, 1) or not bias:
-            raise NotImplementedError('tam_gcn_amd: ConvTemporalGraphical is built for the 1x1 form with bias (as st_gcn uses it)')
         self.kernel_size = kernel_size
+        self._cfg = (t_kernel_size, t_stride, t_dilation, t_padding)
         self.conv = nn.Conv2d(in_channels, out_channels * kernel_size, kernel_size=(t_kernel_size, 1), padding=(t_padding, 0),
                               stride=(t_stride, 1), dilation=(t_dilation, 1), bias=bias)
+
+    def forward(self, x, A):
+        assert A.size(0) == self.kernel_size
+        x = _require_hip(x)
+        bias = self.conv.bias if self.conv.bias is not None else torch.zeros(self.conv.out_channels, device=x.device)
+        h = Fn.TemporalConvFn.run(self._cfg, x, self.conv.weight, bias)
+        n, kc, t, v = h.size()
+        h = h.view(n, self.kernel_size, kc // self.kernel_size, t, v)
+        return torch.einsum('nkctv,kvw->nctw', (h, A)).contiguous(), A
 
 
 class st_gcn(nn.Module):

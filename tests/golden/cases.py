@@ -50,9 +50,12 @@ MODULE_CASES = [
     # round 3: V = 64 beyond ONE 32-frame chunk of the streaming kernels (ctrgc_agg_fwd/bwd, ctrgc_de_acc_mfma) and of the
     # joint-sliced k x 1 convolutions with their 8 halo frames: three chunks with a ragged tail (80 = 32 + 32 + 16,
     # 72 = 32 + 32 + 8); config 4 itself is T = 512 (tests/test_gpu_configs.py holds its full-size properties)
+    # (input seeds 37 / 63: with 4.7e6 / 1.3e6 ReLU inputs per case, the seed 16 the other unit cases use leaves one within
+    # 4e-7 / 1e-7 of zero in the fp64 evaluation -- any fp32 evaluation flips that mask and moves dx by 1 %; these seeds keep
+    # every ReLU input and every max-pool runner-up >= 2.2e-6 / 5.2e-6 away, searched with tests/test_gpu_blocks._Monitor)
     ('ctrgc_64_64_v64_t80',   'CTRGC',        dict(in_channels=64, out_channels=64),                            (1, 64, 80, 64),  11),
-    ('unit_256_256_v64_t72',  'TCN_GCN_unit', dict(in_channels=256, out_channels=256, stride=1, residual=True), (1, 256, 72, 64), 16),
-    ('unit_64_128_s2_v64_t70', 'TCN_GCN_unit', dict(in_channels=64, out_channels=128, stride=2, residual=True), (1, 64, 70, 64),  16),
+    ('unit_256_256_v64_t72',  'TCN_GCN_unit', dict(in_channels=256, out_channels=256, stride=1, residual=True), (1, 256, 72, 64), 37),
+    ('unit_64_128_s2_v64_t70', 'TCN_GCN_unit', dict(in_channels=64, out_channels=128, stride=2, residual=True), (1, 64, 70, 64),  63),
 ]
 
 NEEDS_A = ('unit_gcn', 'TCN_GCN_unit')      # ctor takes the (3,V,V) graph array

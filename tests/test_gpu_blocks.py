@@ -82,7 +82,7 @@ class _Monitor:
         return False
 
 
-def _block_teacher(i, xin, cot, sd):
+def _block_teacher(i, xin, cot, sd, training=True):
     """Well-conditioned fp64 teacher of block i: (x, y, dx, {param: grad}, tries)."""
     pfx = f'l{i}'
     keys = [k for k in sd if k.startswith(pfx + '.')]
@@ -94,7 +94,7 @@ def _block_teacher(i, xin, cot, sd):
         x = x0 if t == 0 else x0 + 1e-3 * scale * make_input(tuple(x0.shape), seed=9000 + 100 * i + t).double()
         sdb = {k: sd[k].detach().clone() for k in keys}
         with torch.no_grad(), _Monitor() as mon:
-            O.tcn_gcn_unit(x, sdb, pfx, stride, residual=res, training=True)
+            O.tcn_gcn_unit(x, sdb, pfx, stride, residual=res, training=training)
         if mon.relu_min >= MARGIN and mon.pool_gap >= MARGIN:
             break
     else:
@@ -104,7 +104,7 @@ def _block_teacher(i, xin, cot, sd):
         if v.is_floating_point() and 'running' not in k:
             v.requires_grad_(True)
     x = x.clone().requires_grad_(True)
-    y = O.tcn_gcn_unit(x, sdb, pfx, stride, residual=res, training=True)
+    y = O.tcn_gcn_unit(x, sdb, pfx, stride, residual=res, training=training)
     y.backward(cot)
     return x.detach(), y.detach(), x.grad, {k[len(pfx) + 1:]: v.grad for k, v in sdb.items() if v.requires_grad}, t
 
@@ -157,22 +157,30 @@ def teachers():
     return {}
 
 
+@pytest.mark.parametrize('bn', ['train', 'eval'])
 @pytest.mark.parametrize('mode', [1, 0], ids=['split_bf16_bwd', 'exact_f32'])
 @pytest.mark.parametrize('tag', BLOCK_CASES)
-def test_every_block_teacher_forced(tag, mode, traces, teachers):
+def test_every_block_teacher_forced(tag, mode, bn, traces, teachers):
+    """bn = 'eval': the same blocks with BatchNorm on its running statistics (autograd through a model in eval() mode: the
+    cross-modal caller, reference models/resnet_gcn_attention.py:82-85) -- the strict backstop of
+    tests/test_gpu_model.py::test_backward_through_eval_mode_matches_the_oracle, whose end-to-end bars must tolerate ReLU flips."""
     from tam_gcn_amd import _lib
+    if bn == 'eval' and tag != BLOCK_CASES[0]:
+        pytest.skip('eval-mode blocks: one model case')
+    training = bn == 'train'
     lib = _lib.load()
     prev = lib.tamgcn_get_split_mode()
     dev = torch.device('cuda:0')
     m, sd, rec = traces[tag]
-    m = m.to(dev).train()
+    m = m.to(dev).train(training)
+    before = {k: b.detach().clone() for k, b in m.named_buffers()}
     f32 = lambda t: t.detach().float().to(dev).contiguous()      # noqa: E731
     failures, tries = [], []
     lib.tamgcn_set_split_mode(mode)
     try:
         for i, xin, hout in rec:
-            tx, ty, tdx, tgrads, t = teachers[(tag, i)] if (tag, i) in teachers else teachers.setdefault(
-                (tag, i), _block_teacher(i, xin, hout.grad, sd))
+            tx, ty, tdx, tgrads, t = teachers[(tag, i, bn)] if (tag, i, bn) in teachers else teachers.setdefault(
+                (tag, i, bn), _block_teacher(i, xin, hout.grad, sd, training))
             tries.append(t)
             blk = getattr(m, f'l{i}')
             for p in blk.parameters():
@@ -209,5 +217,7 @@ def test_every_block_teacher_forced(tag, mode, traces, teachers):
                     failures.append(f'l{i}.{k} {e:.2e}')
     finally:
         lib.tamgcn_set_split_mode(prev)
-    print(f'{tag} mode {mode}: teacher nudges per block {tries}')
-    assert not failures, f'{tag} mode {mode}: ' + '; '.join(failures[:40])
+    print(f'{tag} mode {mode} bn {bn}: teacher nudges per block {tries}')
+    assert not failures, f'{tag} mode {mode} bn {bn}: ' + '; '.join(failures[:40])
+    if not training:
+        assert all(torch.equal(b, before[k]) for k, b in m.named_buffers()), 'running statistics changed in eval mode'

@@ -150,3 +150,34 @@ def test_block_with_active_dropout(case, monkeypatch):
     with torch.no_grad():
         xe = make_input(shape, xseed).to(dev)
         assert torch.equal(blk(xe, A.to(dev))[0], ref(xe, A.to(dev))[0])
+
+
+@pytest.mark.parametrize('cfg', [dict(), dict(t_kernel_size=3, t_padding=1), dict(t_kernel_size=5, t_stride=2, t_padding=4, t_dilation=2),
+                                 dict(t_stride=2), dict(bias=False)], ids=['1x1', 'k3', 'k5_s2_d2', '1x1_s2', 'no_bias'])
+def test_graph_convolution_called_on_its_own(cfg):
+    """ConvTemporalGraphical.forward(x, A) outside st_gcn, in every form its constructor offers (reference
+    models/stgcn.py:37-64), against the same arithmetic in fp64 torch: output and every gradient."""
+    dev = torch.device('cuda:0')
+    torch.manual_seed(5)
+    Cin, Cout, K, T, V = 16, 32, 3, 14, 20
+    gc = M.ConvTemporalGraphical(Cin, Cout, K, **cfg)
+    ref = torch.nn.Conv2d(Cin, Cout * K, kernel_size=(cfg.get('t_kernel_size', 1), 1), padding=(cfg.get('t_padding', 0), 0),
+                          stride=(cfg.get('t_stride', 1), 1), dilation=(cfg.get('t_dilation', 1), 1), bias=cfg.get('bias', True)).double()
+    ref.load_state_dict({k: v.double() for k, v in gc.conv.state_dict().items()})
+    x = make_input((2, Cin, T, V), seed=3)
+    Ar = (A + 0.1 * make_input((K, V, V), seed=4))
+    xo, Ao = x.double().requires_grad_(True), Ar.double().requires_grad_(True)
+    ho = ref(xo)
+    n, kc, t, v = ho.shape
+    yo = torch.einsum('nkctv,kvw->nctw', ho.view(n, K, kc // K, t, v), Ao)
+    cot = make_input(tuple(yo.shape), seed=COT_SEED)
+    (yo * cot.double()).sum().backward()
+    gc = gc.to(dev)
+    xg, Ag = x.to(dev).requires_grad_(True), Ar.to(dev).requires_grad_(True)
+    y, A_out = gc(xg, Ag)
+    (y * cot.to(dev)).sum().backward()
+    assert A_out is Ag
+    _cmp('y', y, yo.detach(), 1e-5); _cmp('dx', xg.grad, xo.grad, 2e-5); _cmp('dA', Ag.grad, Ao.grad, 2e-5)
+    _cmp('dW', gc.conv.weight.grad, ref.weight.grad, 2e-5)
+    if cfg.get('bias', True):
+        _cmp('db', gc.conv.bias.grad, ref.bias.grad, 2e-5)

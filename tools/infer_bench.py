@@ -1,5 +1,6 @@
 """GPU-box tool: forward-only throughput (eval mode, no_grad) of the N-UCLA model at a few batch sizes -- what the
-inference-only callers (cross-modal attention, ensemble eval, visualisation) see.  Eager launches and HIP-graph replay."""
+inference-only callers (cross-modal attention, ensemble eval, visualisation) see.  Eager launches and HIP-graph replay.
+    python tools/infer_bench.py [batch ...]        (default 1 16 256)"""
 import os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,7 +12,7 @@ with torch.no_grad():
     for k, p in m.named_parameters():
         if k.endswith('alpha'):
             p.fill_(0.5)
-for B in (1, 16, 256):
+for B in ([int(v) for v in sys.argv[1:]] or (1, 16, 256)):
     x = torch.rand(B, 3, 64, 20, 1, device=dev) * 2 - 1
     with torch.no_grad():
         for _ in range(3):
