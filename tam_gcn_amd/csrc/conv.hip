@@ -624,13 +624,6 @@ __global__ __launch_bounds__(G_NT, 2) void conv1x1_glds_kernel(const ConvArgs a,
     const int ncols = bt * V;
     const long long TV = (long long)a.T_in * V;
 
-    for (int e = tid; e < K; e += G_NT) {
-        int ch = a.src.coff + e;
-        cf[e] = a.src.coef ? a.src.coef[ch] : 1.f;
-        cf[K + e] = (a.src.coef && a.src.x2) ? a.src.coef[a.src.ctot + ch] : 0.f;
-        cf[2 * K + e] = a.src.coef ? a.src.coef[2 * a.src.ctot + ch] : 0.f;
-    }
-
     // ---- per-lane DMA descriptors (the same for every chunk)
     const int NQ = (LB + 63) >> 6;                                // 1 KB pieces per 4-row group
     const int NI1 = (BK / 4) * NQ;                                // pieces per source and chunk
@@ -729,10 +722,16 @@ __global__ __launch_bounds__(G_NT, 2) void conv1x1_glds_kernel(const ConvArgs a,
     const float lo = a.src.act == 1 ? 0.f : -__builtin_inff();
 
     TG_T(tt0);
-    __syncthreads();                                              // cf visible (no DMA in flight yet)
     const int nch = K / BK;
-    issue(0);
-    if (nch > 1) issue(1);
+    issue(0);                                                     // the first two chunks travel while the prologue coefficients are
+    if (nch > 1) issue(1);                                        // fetched (they used to wait for that round trip: 0-7 % per launch, K = 256)
+    for (int e = tid; e < K; e += G_NT) {
+        int ch = a.src.coff + e;
+        cf[e] = a.src.coef ? a.src.coef[ch] : 1.f;
+        cf[K + e] = (a.src.coef && a.src.x2) ? a.src.coef[a.src.ctot + ch] : 0.f;
+        cf[2 * K + e] = a.src.coef ? a.src.coef[2 * a.src.ctot + ch] : 0.f;
+    }
+    __syncthreads();                                              // cf visible (this barrier also waits for the two chunks)
     TG_T(tt1); TG_ACC(0, tt1 - tt0);
     for (int c = 0; c < nch; ++c) {
         TG_T(ta);

@@ -73,7 +73,8 @@ struct Plan {
     static constexpr int STAGE = G::SBK * G::PITCHB + NRT * 16 * G::SBKP;
     static constexpr int X3T = NR * G::PX3;
     static constexpr int REGION = ((STAGE > X3T ? STAGE : X3T) + 3) & ~3;      // the stage aliases the x3 tile
-    static constexpr size_t LDS = sizeof(float) * ((size_t)NR * G::VV + REGION + (size_t)G::CT * G::NCOLS);
+    static constexpr int ETILE = (NR * G::VV + 255) & ~255;                    // E tiles, whole 1 KB DMA pieces
+    static constexpr size_t LDS = sizeof(float) * ((size_t)ETILE + REGION + (size_t)G::CT * G::NCOLS);
 };
 
 // blockIdx -> (n, channel tile); blocks that share n are b, b+8, ... => same XCD / L2
@@ -90,28 +91,33 @@ __device__ __forceinline__ bool block_coords(const CtrgcArgs& a, int& n, int& c0
 // Ek[c][u][s*V + v] (one row of KP = S*V floats per (channel, joint u)):
 // row u of a channel is the B operand's k axis, contiguous for 16-byte fragment reads; rows are 240 B apart at S = 3, V = 20,
 // i.e. 15 sixteen-byte slots: the sixteen rows a fragment read touches sit in sixteen different slots of the bank row.
+// The tiles travel by LDS-DMA (global_load_lds, 16 bytes per lane, 1 KB per wave instruction): the LDS image of a piece
+// is linear, so the layout change sits in the per-lane SOURCE address; no registers, no LDS store instructions, and the
+// transfer overlaps whatever the workgroup requests next (the first operand chunk).  It is complete at the first
+// __syncthreads() after the call (hipcc drains outstanding LDS-DMA there) -- the caller's first barrier.
+typedef __attribute__((address_space(1))) const void* cg_gptr;
+typedef __attribute__((address_space(3))) void* cg_lptr;
+
 template <class G, int ST>
 __device__ __forceinline__ void load_E_k(const float* __restrict__ Eg, int Cout, int n, int c0, float* Ek) {
-    constexpr int V = G::V, VV = G::VV, NT = G::NT, CT = G::CT, KP = ST * V;
-    constexpr int PER = CT * VV / 4;                   // float4 per subset
-    constexpr int NL = (ST * PER + NT - 1) / NT;
-    float4 t[NL];
+    constexpr int V = G::V, VV = G::VV, CT = G::CT, KP = ST * V;
+    constexpr int TOT4 = CT * V * KP / 4;              // float4 of the image
+    constexpr int NPIECE = (TOT4 + 63) / 64, NPW = (NPIECE + G::NW - 1) / G::NW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int i = 0; i < NL; ++i) {
-        const int e = threadIdx.x + i * NT;
-        const int sidx = (e < ST * PER ? e : 0) / PER, r = (e < ST * PER ? e : 0) - sidx * PER;
-        t[i] = reinterpret_cast<const float4*>(Eg + (((long long)n * ST + sidx) * Cout + c0) * VV)[r];
-    }
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-        const int e = threadIdx.x + i * NT;
-        if (e < ST * PER) {
-            const int sidx = e / PER, r = e - sidx * PER;          // r: float4 index inside [c][u][v]
-            const int cu = (r * 4) / V, v = r * 4 - cu * V;        // cu = c*V + u
-            *reinterpret_cast<float4*>(Ek + cu * KP + sidx * V + v) = t[i];
+    for (int i = 0; i < NPW; ++i) {
+        const int piece = wave * NPW + i;                          // wave-uniform
+        if (piece < NPIECE) {
+            int q = piece * 64 + lane;                             // float4 index inside the image [c][u][s*V + v]
+            if (q >= TOT4) q = TOT4 - 1;                           // tail lanes of the last piece land in the region's padding
+            const int f = 4 * q;
+            const int cu = f / KP, k = f - cu * KP;                // cu = c*V + u
+            const int sidx = k / V, v = k - sidx * V;
+            const int c = cu / V, u = cu - c * V;
+            const float* gp = Eg + (((long long)n * ST + sidx) * Cout + c0 + c) * VV + u * V + v;
+            __builtin_amdgcn_global_load_lds((cg_gptr)gp, (cg_lptr)(Ek + piece * 256), 16, 0, 0);
         }
     }
-    __syncthreads();
 }
 
 // ---------------------------------------------------------------------------
@@ -465,7 +471,7 @@ __global__ __launch_bounds__(G::NT, 2) void ctrgc_fwd_kernel(const CtrgcArgs a, 
     int n, c0;
     if (!block_coords<G>(a, n, c0)) return;
     float* Es = smem;                                  // [CT][V][S*V]: row (c, u) = E_s[c][u][v] over (s, v)
-    float* X3 = Es + P::NR * G::VV;                    // REGION floats: GEMM stage, then the x3 tile [CT][BT][S*V]
+    float* X3 = Es + P::ETILE;                         // REGION floats: GEMM stage, then the x3 tile [CT][BT][S*V]
     float* Zs = X3 + P::REGION;                        // [CT][NCOLS]
     const int tid = threadIdx.x;
     const int c = tid / (G::NTQ * 4);
@@ -597,7 +603,7 @@ __global__ __launch_bounds__(G::NT, 2) void ctrgc_bwd_dx3_kernel(const CtrgcArgs
     int n, c0;
     if (!block_coords<G>(a, n, c0)) return;
     float* Es = smem;                                  // [CT][V][S*V], the forward's layout
-    float* X3 = Es + P::NR * G::VV;                    // output staging [S*CT][PX3]
+    float* X3 = Es + P::ETILE;                         // output staging [S*CT][PX3]
     float* Zs = X3 + P::REGION;                        // dy chunk [CT][NCOLS]
     const int tid = threadIdx.x;
     const int c = tid / (G::NTQ * 4);

@@ -104,6 +104,9 @@ def _side_ok(device, main):
     return True
 
 
+BLOCK_FORK = os.environ.get('TAMGCN_BLOCK_FORK', '1') != '0'    # one fork per block backward (A/B knob of round 3)
+
+
 class Fork:
     """with Fork(device, k) as f:  f.on(i) -> context running on side stream i; joins on exit."""
 
@@ -111,6 +114,12 @@ class Fork:
         self.main = torch.cuda.current_stream(device)
         self.side = _side_streams(device, self.main, k) if _side_ok(device, self.main) else []
         self.used = set()
+        self.keep = []                                 # operands of side-stream work whose Python owners may go away before the join
+
+    def hold(self, *objs):
+        """Keep tensors alive until the join: a block freed on the main stream while a side-stream kernel still reads it
+        would be handed to the next allocation on the main stream."""
+        self.keep.extend(o for o in objs if o is not None)
 
     def on(self, i):
         if not self.side:
@@ -150,6 +159,7 @@ class Fork:
         for i in self.used:
             self.main.wait_stream(self.side[i])        # join
         self.used.clear()
+        self.keep = []
         return False
 
 
@@ -334,15 +344,19 @@ def gcn_backward(P, sv, dg, need_dx=True, extra_dx=None):
         return _gcn_backward(P, sv, dg, need_dx, extra_dx)
 
 
-def _gcn_backward(P, sv, dg, need_dx=True, extra_dx=None):
+def _gcn_backward(P, sv, dg, need_dx=True, extra_dx=None, fk=None):
     x, xbar, pq, y_pre, d_pre, o_pre, g = sv['x'], sv['xbar'], sv['pq'], sv['y_pre'], sv['d_pre'], sv['o_pre'], sv['g']
     training = sv['training']
     N, Cin, T, V = x.shape
     S_, R, Cout = P.S, P.R, P.Cout
     count = N * T * V
     G = {}
-    fk = Fork(x.device, 2)
-    fk.__enter__()
+    own = fk is None
+    if own:
+        fk = Fork(x.device, 2)
+        fk.__enter__()
+    else:
+        fk.refork()                                    # side streams the caller used already: they see dg
     # tail: relu, tanh(BN(offset conv))
     dsum, doz, part_o = ops.gcn_tail_bwd(dg, g, S(o_pre, coef=sv['coef_o']), sv['save_o'])
     coefb_o = torch.empty(3, Cout, device=x.device)
@@ -398,7 +412,10 @@ def _gcn_backward(P, sv, dg, need_dx=True, extra_dx=None):
             G['Wd'] = ops.wgrad(gyd, xs, M=Cout, K=Cin)
         if need_dx:
             ops.conv(gyd, K=Cout, w=P.Wd, bias=None, M=Cin, wmode=1, add1=dx, y=dx)
-    fk.__exit__()
+    if own:
+        fk.__exit__()
+    else:
+        fk.hold(doz, coefb_o, ddiff, dyb, coefb_y, dres, coefb_d, dx3, dpq)
     return dx, G
 
 
@@ -535,9 +552,13 @@ def tcn_backward(P, sv, dout, need_dg=True, need_dxres=True):
         return _tcn_backward(P, sv, dout, need_dg, need_dxres)
 
 
-def _tcn_backward(P, sv, dout, need_dg=True, need_dxres=True):
+def _tcn_backward(P, sv, dout, need_dg=True, need_dxres=True, fk=None):
     """Returns (dg, dxres, grads).  dxres is None for rmode 'zero'; for 'identity' it is the
-    masked upstream gradient itself (caller adds it)."""
+    masked upstream gradient itself (caller adds it).
+
+    fk: a Fork shared with the caller (TCN_GCN_unit's backward, four side streams): the weight gradients then go to side
+    streams 2 / 3 and are NOT joined here -- they run beside the unit_gcn backward that follows and are joined, with
+    their slab reductions, at the end of the block's autograd node; their operands are held until then (Fork.hold)."""
     g, xres, h_pre, cat_pre, r_pre, out = sv['g'], sv['xres'], sv['h_pre'], sv['cat_pre'], sv['r_pre'], sv['out']
     training = sv['training']
     N, Cin, T, V = g.shape
@@ -546,8 +567,11 @@ def _tcn_backward(P, sv, dout, need_dg=True, need_dxres=True):
     cnt1, cnt2 = N * T * V, N * T2 * V
     Ch = (nb + 1) * Cb
     G = {}
-    fk = Fork(g.device, 2)
-    fk.__enter__()
+    own = fk is None
+    if own:
+        fk = Fork(g.device, 2)
+        fk.__enter__()
+    W0 = 0 if own else 2                                # side streams of the weight gradients
     dz, part = ops.add_act_bwd(dout, out, P.relu, cat_pre, sv['save_c'], r_pre, sv['save_r'], want_dz=bool(P.relu))
     if dz is None:
         dz = dout
@@ -596,7 +620,7 @@ def _tcn_backward(P, sv, dout, need_dg=True, need_dxres=True):
             marks.append(fk.mark(b))                   # dh slice and moments of branch b done (its wgrad is not awaited)
         G['bn_in'].append((dgam, dbet))
         dbin.append(dbias)
-        with fk.on(b):
+        with fk.on(W0 + (b & 1)):
             G['Wt'].append(ops.wgrad(gcat(b * Cb), S(h_pre, coef=sv['coef_h'], coff=b * Cb, act=RELU), M=Cb, K=Cb,
                                      KT=k, dil=d, stride=s, pad=pad))
     hp = ops.maxpool_bwd(gcat(nb * Cb), S(h_pre, coef=sv['coef_h'], coff=nb * Cb, act=RELU), sv['save_h'], Cb, s, dh,
@@ -611,9 +635,9 @@ def _tcn_backward(P, sv, dout, need_dg=True, need_dxres=True):
     gs = S(g)
     gyh = S(dh, h_pre, coefb_h)
     fk.refork()                                        # dh and its BN-backward coefficients are ready
-    with fk.on(0):
+    with fk.on(W0):
         G['Win'] = ops.wgrad(gyh, gs, M=Ch, K=Cin, rows=[Cb] * (nb + 1))
-    with fk.on(1):
+    with fk.on(W0 + 1):
         G['Wl'] = ops.wgrad(gcat((nb + 1) * Cb), gs, M=Cb, K=Cin, stride=s)
     dg = None
     if need_dg:
@@ -627,8 +651,9 @@ def _tcn_backward(P, sv, dout, need_dg=True, need_dxres=True):
         rk = P.rk
         rpad = (rk - 1) // 2
         fk.refork()
-        with fk.on(1):
+        with fk.on(W0 + 1):
             G['Wr'] = ops.wgrad(gyr, S(xres), M=Cout, K=xres.shape[1], KT=rk, stride=s, pad=rpad)
+        fk.hold(coefb_r)
         if need_dxres:
             Tx = xres.shape[2]
             if rk == 1:
@@ -637,7 +662,10 @@ def _tcn_backward(P, sv, dout, need_dg=True, need_dxres=True):
             else:
                 dxres, _ = ops.conv(gyr, K=Cout, w=P.Wr, bias=None, M=xres.shape[1], KT=rk, stride=1,
                                     pad=(rk - 1) - rpad, wmode=1, up=s, T_out=Tx)
-    fk.__exit__()
+    if own:
+        fk.__exit__()
+    else:
+        fk.hold(dz, coefb_c, dh, coefb_h)              # (the saved tensors stay alive in the caller's ctx until the join)
     return dg, dxres, G
 
 
@@ -724,10 +752,21 @@ class TCNGCNUnitFn(_Fn):
     @staticmethod
     def backward(ctx, dout, _drm=None):
         need_dx = ctx.needs_input_grad[1]
-        dg, dxres, Gt = tcn_backward(ctx.Pt, ctx.svt, dout.contiguous(), need_dg=True, need_dxres=need_dx)
-        ctx.svt = None
-        dx, Gg = gcn_backward(ctx.Pg, ctx.svg, dg, need_dx=need_dx, extra_dx=dxres)
-        ctx.svg = None
+        dout = dout.contiguous()
+        # ONE fork and ONE slab reduction for the whole block: the temporal part's weight gradients (side streams 2 / 3) run
+        # beside the graph part's backward instead of being joined in front of it
+        if not BLOCK_FORK:
+            dg, dxres, Gt = tcn_backward(ctx.Pt, ctx.svt, dout, need_dg=True, need_dxres=need_dx)
+            dx, Gg = gcn_backward(ctx.Pg, ctx.svg, dg, need_dx=need_dx, extra_dx=dxres)
+            ctx.svt = ctx.svg = None
+            return (None, dx, None, None) + tuple(ctx.mod.gcn1._route(Gg)) + tuple(ctx.mod._route_tcn(Gt))
+        with ops.ReduceBatch():
+            fk = Fork(dout.device, 4)
+            dg, dxres, Gt = _tcn_backward(ctx.Pt, ctx.svt, dout, need_dg=True, need_dxres=need_dx, fk=fk)
+            dx, Gg = _gcn_backward(ctx.Pg, ctx.svg, dg, need_dx=need_dx, extra_dx=dxres, fk=fk)
+            fk.hold(dout, dg, dxres)
+            fk.__exit__()                               # join: every operand of the side-stream work may go now
+        ctx.svt = ctx.svg = None
         return (None, dx, None, None) + tuple(ctx.mod.gcn1._route(Gg)) + tuple(ctx.mod._route_tcn(Gt))
 
 

@@ -173,6 +173,9 @@ def test_every_block_teacher_forced(tag, mode, bn, traces, teachers):
     dev = torch.device('cuda:0')
     m, sd, rec = traces[tag]
     m = m.to(dev).train(training)
+    with torch.no_grad():                                  # the train-mode runs of this module moved its running statistics:
+        for k, b in m.named_buffers():                     # the eval teacher uses the fixture's, put them back
+            b.copy_(sd[k].to(b.dtype))
     before = {k: b.detach().clone() for k, b in m.named_buffers()}
     f32 = lambda t: t.detach().float().to(dev).contiguous()      # noqa: E731
     failures, tries = [], []

@@ -161,10 +161,10 @@ def test_harness_sgd_steps(flat, fix, golden_models):
 
     'sgd3b' (lr 0.01, 64 clips x 32 frames): losses and every tensor of the final state (parameters, running
     statistics) within 1e-3 (+ the reference's own fp32-vs-fp64 noise).  The two 4-clip fixtures have 1040 positions per
-    channel and are chaotic at fp32 resolution: ONE ReLU-mask flip moves a gradient by ~1e-2, the conv1 / conv2 biases (which
-    enter only through p_u - q_v) by tens of per cent after three steps -- any change of summation order in a forward kernel
-    (two were tried this round) lands elsewhere, as do the reference's own two precisions.  They pin what is determinate:
-    the first loss (a pure forward, 1e-4), the second (one update, 2e-2) and the key set / finiteness of the final state;
+    channel and are chaotic at fp32 resolution: the fp64 trajectory has ReLU inputs within 1e-6 of zero at every step, ONE mask
+    of the first forward differs on the HIP path (shown, not assumed: tools/sgd_fixture_report.py ->
+    profiles/r03_sgd_fixture_report.txt) and the trajectories separate from there.  They pin the first loss (a pure forward,
+    1e-4), the second and third losses and every state tensor within about twice the measured deviations;
     tests/test_gpu_blocks.py holds every block's gradients to 1e-5 once flips are excluded."""
     from cases import SGD_CASES
     from tam_gcn_amd.distributed import ParamArena, SGDNesterov
@@ -194,11 +194,19 @@ def test_harness_sgd_steps(flat, fix, golden_models):
         opt.step()
         losses.append(float(loss.detach()))
     ref, ref64 = golden_models[f'{fix}/losses'], golden_models[f'{fix}/losses64']
+    # Measured deviations from the fp64 reference on MI355X (profiles/r03_sgd_fixture_report.txt), identical in the exact-fp32
+    # and the split mode: loss[1] 2.1e-3 (sgd3s) / 1.4e-3 (sgd3), loss[2] 5.4e-2 / 2.0e-1; state tensors of >= 256 elements
+    # 2.3e-2 / 1.2e-1, smaller ones up to 1.3e-1..3.2e-1 / 3.5e-1..6.0e-1.  Cause on record: ONE ReLU mask of the first forward
+    # (l4's output, fp64 pre-activation 1.39e-6) differs from fp64.  Bounds = those figures x ~2.
+    LOSS1 = {'sgd3s': 5e-3, 'sgd3': 5e-3}
+    LOSS2 = {'sgd3s': 1.2e-1, 'sgd3': 4e-1}
+    BIG = {'sgd3s': 6e-2, 'sgd3': 2.5e-1}
     if fix == 'sgd3b':
         ltol = 1e-3 * np.abs(ref64) + NOISE_K * np.abs(ref - ref64)
         assert (np.abs(np.array(losses) - ref64) <= ltol).all(), (losses, ref, ref64)
     else:
-        assert abs(losses[1] - ref64[1]) <= 2e-2 * abs(ref64[1]), (losses, ref64)
+        assert abs(losses[1] - ref64[1]) <= LOSS1[fix] * abs(ref64[1]), (losses, ref64)
+        assert abs(losses[2] - ref64[2]) <= LOSS2[fix] * abs(ref64[2]), (losses, ref64)
         assert np.isfinite(losses).all()
     assert abs(losses[0] - ref[0]) <= 1e-4                                       # the first loss is a pure forward
     sd = m.state_dict()
@@ -214,9 +222,9 @@ def test_harness_sgd_steps(flat, fix, golden_models):
         # flip anywhere upstream moves by per cent (the reference's own two precisions differ by up to 2.3 % on them)
         bad = np.abs(got[:, 1] - refd64[:, 1]) > np.where(small, 2e-2, 1e-3) * np.abs(refd64[:, 1]) + NOISE_K * noise + 2e-4
     else:
-        # chaotic fixtures: only tensors of >= 256 elements, within 25 % (the oracle, bit-compatible arithmetic, reproduces
-        # both fixtures to 2e-4: tests/test_model_cpu.py)
-        bad = (~small) & (np.abs(got[:, 1] - refd64[:, 1]) > 0.25 * np.abs(refd64[:, 1]) + 1e-2)
+        # chaotic fixtures (see above): tensors of >= 256 elements within BIG, the cancelling-sum tensors below that size
+        # within 100 % (the oracle, bit-compatible arithmetic, reproduces both fixtures to 2e-4: tests/test_model_cpu.py)
+        bad = np.abs(got[:, 1] - refd64[:, 1]) > np.where(small, 1.0, BIG[fix]) * np.abs(refd64[:, 1]) + 1e-2
         assert np.isfinite(got).all()
     assert not bad.any(), [(k, got[i, 1], refd[i, 1], refd64[i, 1]) for i, k in enumerate(sd.keys()) if bad[i]][:5]
 
