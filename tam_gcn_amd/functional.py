@@ -104,9 +104,6 @@ def _side_ok(device, main):
     return True
 
 
-BLOCK_FORK = os.environ.get('TAMGCN_BLOCK_FORK', '1') != '0'    # one fork per block backward (A/B knob of round 3)
-
-
 class Fork:
     """with Fork(device, k) as f:  f.on(i) -> context running on side stream i; joins on exit."""
 
@@ -114,12 +111,6 @@ class Fork:
         self.main = torch.cuda.current_stream(device)
         self.side = _side_streams(device, self.main, k) if _side_ok(device, self.main) else []
         self.used = set()
-        self.keep = []                                 # operands of side-stream work whose Python owners may go away before the join
-
-    def hold(self, *objs):
-        """Keep tensors alive until the join: a block freed on the main stream while a side-stream kernel still reads it
-        would be handed to the next allocation on the main stream."""
-        self.keep.extend(o for o in objs if o is not None)
 
     def on(self, i):
         if not self.side:
@@ -159,7 +150,6 @@ class Fork:
         for i in self.used:
             self.main.wait_stream(self.side[i])        # join
         self.used.clear()
-        self.keep = []
         return False
 
 
@@ -344,19 +334,15 @@ def gcn_backward(P, sv, dg, need_dx=True, extra_dx=None):
         return _gcn_backward(P, sv, dg, need_dx, extra_dx)
 
 
-def _gcn_backward(P, sv, dg, need_dx=True, extra_dx=None, fk=None):
+def _gcn_backward(P, sv, dg, need_dx=True, extra_dx=None):
     x, xbar, pq, y_pre, d_pre, o_pre, g = sv['x'], sv['xbar'], sv['pq'], sv['y_pre'], sv['d_pre'], sv['o_pre'], sv['g']
     training = sv['training']
     N, Cin, T, V = x.shape
     S_, R, Cout = P.S, P.R, P.Cout
     count = N * T * V
     G = {}
-    own = fk is None
-    if own:
-        fk = Fork(x.device, 2)
-        fk.__enter__()
-    else:
-        fk.refork()                                    # side streams the caller used already: they see dg
+    fk = Fork(x.device, 2)
+    fk.__enter__()
     # tail: relu, tanh(BN(offset conv))
     dsum, doz, part_o = ops.gcn_tail_bwd(dg, g, S(o_pre, coef=sv['coef_o']), sv['save_o'])
     coefb_o = torch.empty(3, Cout, device=x.device)
@@ -412,10 +398,7 @@ def _gcn_backward(P, sv, dg, need_dx=True, extra_dx=None, fk=None):
             G['Wd'] = ops.wgrad(gyd, xs, M=Cout, K=Cin)
         if need_dx:
             ops.conv(gyd, K=Cout, w=P.Wd, bias=None, M=Cin, wmode=1, add1=dx, y=dx)
-    if own:
-        fk.__exit__()
-    else:
-        fk.hold(doz, coefb_o, ddiff, dyb, coefb_y, dres, coefb_d, dx3, dpq)
+    fk.__exit__()
     return dx, G
 
 
@@ -552,13 +535,9 @@ def tcn_backward(P, sv, dout, need_dg=True, need_dxres=True):
         return _tcn_backward(P, sv, dout, need_dg, need_dxres)
 
 
-def _tcn_backward(P, sv, dout, need_dg=True, need_dxres=True, fk=None):
+def _tcn_backward(P, sv, dout, need_dg=True, need_dxres=True):
     """Returns (dg, dxres, grads).  dxres is None for rmode 'zero'; for 'identity' it is the
-    masked upstream gradient itself (caller adds it).
-
-    fk: a Fork shared with the caller (TCN_GCN_unit's backward, four side streams): the weight gradients then go to side
-    streams 2 / 3 and are NOT joined here -- they run beside the unit_gcn backward that follows and are joined, with
-    their slab reductions, at the end of the block's autograd node; their operands are held until then (Fork.hold)."""
+    masked upstream gradient itself (caller adds it)."""
     g, xres, h_pre, cat_pre, r_pre, out = sv['g'], sv['xres'], sv['h_pre'], sv['cat_pre'], sv['r_pre'], sv['out']
     training = sv['training']
     N, Cin, T, V = g.shape
@@ -567,11 +546,8 @@ def _tcn_backward(P, sv, dout, need_dg=True, need_dxres=True, fk=None):
     cnt1, cnt2 = N * T * V, N * T2 * V
     Ch = (nb + 1) * Cb
     G = {}
-    own = fk is None
-    if own:
-        fk = Fork(g.device, 2)
-        fk.__enter__()
-    W0 = 0 if own else 2                                # side streams of the weight gradients
+    fk = Fork(g.device, 2)
+    fk.__enter__()
     dz, part = ops.add_act_bwd(dout, out, P.relu, cat_pre, sv['save_c'], r_pre, sv['save_r'], want_dz=bool(P.relu))
     if dz is None:
         dz = dout
@@ -620,7 +596,7 @@ def _tcn_backward(P, sv, dout, need_dg=True, need_dxres=True, fk=None):
             marks.append(fk.mark(b))                   # dh slice and moments of branch b done (its wgrad is not awaited)
         G['bn_in'].append((dgam, dbet))
         dbin.append(dbias)
-        with fk.on(W0 + (b & 1)):
+        with fk.on(b):
             G['Wt'].append(ops.wgrad(gcat(b * Cb), S(h_pre, coef=sv['coef_h'], coff=b * Cb, act=RELU), M=Cb, K=Cb,
                                      KT=k, dil=d, stride=s, pad=pad))
     hp = ops.maxpool_bwd(gcat(nb * Cb), S(h_pre, coef=sv['coef_h'], coff=nb * Cb, act=RELU), sv['save_h'], Cb, s, dh,
@@ -635,9 +611,9 @@ def _tcn_backward(P, sv, dout, need_dg=True, need_dxres=True, fk=None):
     gs = S(g)
     gyh = S(dh, h_pre, coefb_h)
     fk.refork()                                        # dh and its BN-backward coefficients are ready
-    with fk.on(W0):
+    with fk.on(0):
         G['Win'] = ops.wgrad(gyh, gs, M=Ch, K=Cin, rows=[Cb] * (nb + 1))
-    with fk.on(W0 + 1):
+    with fk.on(1):
         G['Wl'] = ops.wgrad(gcat((nb + 1) * Cb), gs, M=Cb, K=Cin, stride=s)
     dg = None
     if need_dg:
@@ -651,9 +627,8 @@ def _tcn_backward(P, sv, dout, need_dg=True, need_dxres=True, fk=None):
         rk = P.rk
         rpad = (rk - 1) // 2
         fk.refork()
-        with fk.on(W0 + 1):
+        with fk.on(1):
             G['Wr'] = ops.wgrad(gyr, S(xres), M=Cout, K=xres.shape[1], KT=rk, stride=s, pad=rpad)
-        fk.hold(coefb_r)
         if need_dxres:
             Tx = xres.shape[2]
             if rk == 1:
@@ -662,10 +637,7 @@ def _tcn_backward(P, sv, dout, need_dg=True, need_dxres=True, fk=None):
             else:
                 dxres, _ = ops.conv(gyr, K=Cout, w=P.Wr, bias=None, M=xres.shape[1], KT=rk, stride=1,
                                     pad=(rk - 1) - rpad, wmode=1, up=s, T_out=Tx)
-    if own:
-        fk.__exit__()
-    else:
-        fk.hold(dz, coefb_c, dh, coefb_h)              # (the saved tensors stay alive in the caller's ctx until the join)
+    fk.__exit__()
     return dg, dxres, G
 
 
@@ -752,21 +724,10 @@ class TCNGCNUnitFn(_Fn):
     @staticmethod
     def backward(ctx, dout, _drm=None):
         need_dx = ctx.needs_input_grad[1]
-        dout = dout.contiguous()
-        # ONE fork and ONE slab reduction for the whole block: the temporal part's weight gradients (side streams 2 / 3) run
-        # beside the graph part's backward instead of being joined in front of it
-        if not BLOCK_FORK:
-            dg, dxres, Gt = tcn_backward(ctx.Pt, ctx.svt, dout, need_dg=True, need_dxres=need_dx)
-            dx, Gg = gcn_backward(ctx.Pg, ctx.svg, dg, need_dx=need_dx, extra_dx=dxres)
-            ctx.svt = ctx.svg = None
-            return (None, dx, None, None) + tuple(ctx.mod.gcn1._route(Gg)) + tuple(ctx.mod._route_tcn(Gt))
-        with ops.ReduceBatch():
-            fk = Fork(dout.device, 4)
-            dg, dxres, Gt = _tcn_backward(ctx.Pt, ctx.svt, dout, need_dg=True, need_dxres=need_dx, fk=fk)
-            dx, Gg = _gcn_backward(ctx.Pg, ctx.svg, dg, need_dx=need_dx, extra_dx=dxres, fk=fk)
-            fk.hold(dout, dg, dxres)
-            fk.__exit__()                               # join: every operand of the side-stream work may go now
-        ctx.svt = ctx.svg = None
+        dg, dxres, Gt = tcn_backward(ctx.Pt, ctx.svt, dout.contiguous(), need_dg=True, need_dxres=need_dx)
+        ctx.svt = None
+        dx, Gg = gcn_backward(ctx.Pg, ctx.svg, dg, need_dx=need_dx, extra_dx=dxres)
+        ctx.svg = None
         return (None, dx, None, None) + tuple(ctx.mod.gcn1._route(Gg)) + tuple(ctx.mod._route_tcn(Gt))
 
 
