@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TAMGCN_VERSION 300          /* round 3: bumped on every change of a struct layout, signature or documented semantics */
+#define TAMGCN_VERSION 310          /* round 3: bumped on every change of a struct layout, signature or documented semantics */
 #define TAMGCN_MAX_SUBSETS 3
 #define TAMGCN_MAX_V 32             /* joints supported by the LDS-resident CTRGC tiles (V in {20, 25}); V in {32, 64}: tamgcn_ctrgc_tiled_* */
 
@@ -371,6 +371,58 @@ int tamgcn_score_fuse(const float* scores, const float* weights, int S, int N, i
 int tamgcn_stream_derive(const float* x, int N, int C, int T, int V, int M, const int* parent, int mode, float* out, void* stream);
 int tamgcn_feeder_transform(const double* raw, const long long* offsets, const double* rot, const int* idx, const int* parent,
                             int N, int V, int time_steps, int center_joint, int mode, float* out, void* stream);
+
+/* ---- f2: the eval-mode TCN_GCN_unit for small batches (callers: reference
+ * ensemble/ensemble_ctrgcn_resnet_eval.py:147-183, models/resnet_gcn_attention.py:82-85, visual.py:53-55 -- model(data)
+ * on 1..16 clips in eval mode).  Five launches per block, each 50..130 workgroups per clip; V = 20, S = 3.  The CALLER folds
+ * every eval-mode BatchNorm into the weights it passes (bn(W x + b) = (s W) x + (s b + t), s = gamma / sqrt(var + eps),
+ * t = beta - mean s) -- tam_gcn_amd/f2.py does.  Reference arithmetic: models/ctrgcn.py:172-177, :252-261 (unit_gcn with
+ * the offset_conv branch), :93-146 (MultiScale_TemporalConv), :281-283 (residual + ReLU of TCN_GCN_unit).
+ *   _f2_e     E (N, S, Cout, V, V) = alpha (W4 tanh(p_u - q_v) + b4) + A with p, q = W12 mean_t(x) + b12  (conv1 / conv2 commute
+ *             with the mean over T: SURVEY.md §8a);  reads x, w12, b12, w4, b4, A, alpha; writes d->E
+ *   _f2_gcn   z = sum_s E_s (W3_s x + b3_s);  y = sy z + ty;  res = 0 | x | wd x + bd (res_mode 0 | 1 | 2);
+ *             writes sum = y + res and diff = res - y, both (N, Cout, T, V); reads d->E
+ *   _f2_gemm  out (N, M, T, V) = epilogue(W x + b), W [M][K] row-major, x (N, K, T, V):
+ *             mode 0: relu(add + tanh(.))            (offset_conv + the block tail :258-261; add = sum, x = diff)
+ *             mode 1: rows < relu_rows: relu(.), others plain  (entry convs of the temporal / pooled branches stacked over the
+ *                     plain 1x1 branch: all read g)
+ *   _f2_tcn   h = _f2_gemm mode 1's output (N, Cout, T, V) with Cout = (nb + 2) Cb: branches b < nb: k x 1 conv (dilation dil[b],
+ *             stride, "same" padding) of rows [b Cb, (b+1) Cb) with wt[b] [Cb][Cb*ks] (tap innermost), + bt[b]; branch nb:
+ *             MaxPool2d((3,1), stride, pad 1) of rows [nb Cb, ..) then sp . + tp; branch nb + 1: rows [(nb+1) Cb, ..) at the
+ *             strided frames; + residual (res_mode 0 none | 1 the block input x | 2 wr x(strided frames) + br); ReLU;
+ *             out (N, Cout, (T - 1) / stride + 1, V). */
+typedef struct tamgcn_f2_gcn_desc {
+    int N, Cin, Cout, T, V, S, R, res_mode;
+    const float* x;                                  /* (N, Cin, T, V) */
+    const float* w12; const float* b12;              /* [S*2R][Cin], [S*2R]: rows s*2R + r = conv1, s*2R + R + r = conv2 */
+    const float* w4; const float* b4;                /* [S][Cout][R], [S][Cout] */
+    const float* A; const float* alpha;              /* [S][V][V], [1] */
+    const float* w3; const float* b3;                /* [S*Cout][Cin], [S*Cout] */
+    const float* sy; const float* ty;                /* [Cout] folded unit_gcn.bn */
+    const float* wd; const float* bd;                /* [Cout][Cin], [Cout] folded down conv + BatchNorm (res_mode 2) or NULL */
+    float* E;                                        /* (N, S, Cout, V, V) */
+    float* sum; float* diff;                         /* (N, Cout, T, V) each (not touched by _f2_e) */
+} tamgcn_f2_gcn_desc;
+int tamgcn_f2_e(const tamgcn_f2_gcn_desc* d, void* stream);
+int tamgcn_f2_gcn(const tamgcn_f2_gcn_desc* d, void* stream);
+
+typedef struct tamgcn_f2_gemm_desc {
+    int N, K, M, T, V, mode, relu_rows;
+    const float* x; const float* w; const float* b; const float* add;
+    float* out;
+} tamgcn_f2_gemm_desc;
+int tamgcn_f2_gemm(const tamgcn_f2_gemm_desc* d, void* stream);
+
+typedef struct tamgcn_f2_tcn_desc {
+    int N, Cin, Cout, T, V, stride, Cb, nb, ks, res_mode;
+    int dil[4];
+    const float* h;
+    const float* wt[4]; const float* bt[4];
+    const float* sp; const float* tp;
+    const float* x; const float* wr; const float* br;
+    float* out;
+} tamgcn_f2_tcn_desc;
+int tamgcn_f2_tcn(const tamgcn_f2_tcn_desc* d, void* stream);
 
 #ifdef __cplusplus
 }

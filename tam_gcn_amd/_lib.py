@@ -66,6 +66,23 @@ class CtrgcDesc(C.Structure):
                 ('b4', C.c_void_p), ('A', C.c_void_p), ('alpha', C.c_void_p), ('E', C.c_void_p)]
 
 
+class F2GcnDesc(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ('N', 'Cin', 'Cout', 'T', 'V', 'S', 'R', 'res_mode')] + \
+               [(k, C.c_void_p) for k in ('x', 'w12', 'b12', 'w4', 'b4', 'A', 'alpha', 'w3', 'b3', 'sy', 'ty', 'wd', 'bd',
+                                          'E', 'sum', 'diff')]
+
+
+class F2GemmDesc(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ('N', 'K', 'M', 'T', 'V', 'mode', 'relu_rows')] + \
+               [(k, C.c_void_p) for k in ('x', 'w', 'b', 'add', 'out')]
+
+
+class F2TcnDesc(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ('N', 'Cin', 'Cout', 'T', 'V', 'stride', 'Cb', 'nb', 'ks', 'res_mode')] + \
+               [('dil', C.c_int * 4), ('h', C.c_void_p), ('wt', C.c_void_p * 4), ('bt', C.c_void_p * 4)] + \
+               [(k, C.c_void_p) for k in ('sp', 'tp', 'x', 'wr', 'br', 'out')]
+
+
 # name -> (restype, argtypes); must list every symbol of include/tamgcn.h
 _i, _p, _d, _f, _ll = C.c_int, C.c_void_p, C.c_double, C.c_float, C.c_longlong
 _SP = C.POINTER(Src)
@@ -120,6 +137,10 @@ SIGNATURES = {
     'tamgcn_ce_bwd': (_i, [_p, _p, _i, _i, _p, _p]),
     'tamgcn_stream_derive': (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _p, _p]),
     'tamgcn_feeder_transform': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    'tamgcn_f2_e': (_i, [C.POINTER(F2GcnDesc), _p]),
+    'tamgcn_f2_gcn': (_i, [C.POINTER(F2GcnDesc), _p]),
+    'tamgcn_f2_gemm': (_i, [C.POINTER(F2GemmDesc), _p]),
+    'tamgcn_f2_tcn': (_i, [C.POINTER(F2TcnDesc), _p]),
 }
 
 
@@ -128,7 +149,7 @@ class TamgcnLibraryError(RuntimeError):
 
 
 _lib = None
-ABI_VERSION = 300          # include/tamgcn.h TAMGCN_VERSION this binding's structs and signatures were written for
+ABI_VERSION = 310          # include/tamgcn.h TAMGCN_VERSION this binding's structs and signatures were written for
 
 
 def load():

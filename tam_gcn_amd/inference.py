@@ -43,6 +43,9 @@ class GraphedForward:
         # owned by the per-module caches (functional._eval_cached): an eager forward after a parameter change evicts
         # them.  This entry keeps them alive, so a replay without reset() reads stale coefficients, never freed memory.
         keep = [dict(m.__dict__['_tamgcn_eval_cache']) for m in self.model.modules() if '_tamgcn_eval_cache' in m.__dict__]
+        eng = self.model.__dict__.get('_tamgcn_f2')        # small batches: the folded weights of tam_gcn_amd.f2, likewise
+        if eng:
+            keep.append(eng._blocks)
         return g, static_in, out, keep
 
     def __call__(self, x):

@@ -480,8 +480,30 @@ class Model(nn.Module):
             return x, N, M, rm
         return self.l10(x), N, M
 
+    def _f2(self, x):
+        """The small-batch eval engine (tam_gcn_amd.f2) if this call is one for it, else None."""
+        if self.training or torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.float32:
+            return None
+        from .. import f2
+        if not f2.enabled() or (x.shape[0] * (x.shape[4] if x.dim() == 5 else 1)) > f2.F2_MAX_CLIPS:
+            return None
+        eng = self.__dict__.get('_tamgcn_f2')
+        if eng and eng.model is not self:                  # an nn.DataParallel replica carries the original's __dict__: its own engine
+            eng = None
+        if eng is None:
+            try:
+                eng = f2.FusedEval(self)
+                eng._packed(x.device)                      # geometry checks happen here, before anything is launched
+            except f2.Unsupported:
+                eng = False                                # this model is outside the family: the general eval path serves it
+            self.__dict__['_tamgcn_f2'] = eng
+        return eng or None
+
     def forward(self, x):
         x = _require_hip(x)
+        eng = self._f2(x)
+        if eng is not None:
+            return eng(x)
         if isinstance(self.drop_out, nn.Dropout):          # drop_out > 0: pool here, torch's dropout + linear (reference :343-348)
             x, N, M = self._blocks(x)
             x = x.view(N, M, x.size(1), -1).mean(3).mean(1)
@@ -492,7 +514,9 @@ class Model(nn.Module):
         return torch.ops.tamgcn.head(x, self.fc.weight, self.fc.bias, M)
 
     def extract_feature(self, x):
-        x, N, M = self._blocks(_require_hip(x))
+        x = _require_hip(x)
+        eng = self._f2(x)
+        x, N, M = eng.blocks(x) if eng is not None else self._blocks(x)
         _, C, T, V = x.size()
         x = x.view(N, M, C, T, V).permute(0, 2, 3, 4, 1).contiguous()
         return x, x

@@ -358,7 +358,8 @@ def test_eval_fused_path_and_coefficient_cache(monkeypatch):
     statistics made by a training step (whose kernel writes them through raw pointers) and of the affine parameters, and
     launch fewer kernels."""
     from tam_gcn_amd import functional as Fn, _lib
-    dev = torch.device('cuda:0')
+    monkeypatch.setenv('TAMGCN_F2', '0')                   # this test is about the GENERAL eval path (any batch size, any V);
+    dev = torch.device('cuda:0')                           # batches this small otherwise go to tam_gcn_amd.f2 (tests/test_gpu_f2.py)
     m = M.Model(**MODEL_CASES[0][1])
     fill_state_(m.state_dict(), seed=MODEL_PARAM_SEED)
     m = m.to(dev).eval()

@@ -1,6 +1,8 @@
 """GPU-box tool: forward-only throughput (eval mode, no_grad) of the N-UCLA model at a few batch sizes -- what the
 inference-only callers (cross-modal attention, ensemble eval, visualisation) see.  Eager launches and HIP-graph replay.
-    python tools/infer_bench.py [batch ...]        (default 1 16 256)"""
+    python tools/infer_bench.py [--t T] [batch ...]        (default T = 64, batches 1 16 256)
+Batches of at most TAMGCN_F2_MAX_CLIPS clips take the small-batch kernel family (tam_gcn_amd/f2.py); TAMGCN_F2=0 puts them on
+the general eval path for comparison."""
 import os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,13 +14,18 @@ with torch.no_grad():
     for k, p in m.named_parameters():
         if k.endswith('alpha'):
             p.fill_(0.5)
-for B in ([int(v) for v in sys.argv[1:]] or (1, 16, 256)):
-    x = torch.rand(B, 3, 64, 20, 1, device=dev) * 2 - 1
+args = sys.argv[1:]
+T = 64
+if args and args[0] == '--t':
+    T = int(args[1]); args = args[2:]
+print(f'T = {T}, TAMGCN_F2 = {os.environ.get("TAMGCN_F2", "1")}', flush=True)
+for B in ([int(v) for v in args] or (1, 16, 256)):
+    x = torch.rand(B, 3, T, 20, 1, device=dev) * 2 - 1
     with torch.no_grad():
         for _ in range(3):
             y = m(x)
         torch.cuda.synchronize()
-        n = 20
+        n = 50
         t0 = time.perf_counter()
         for _ in range(n):
             y = m(x)
