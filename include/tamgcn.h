@@ -402,6 +402,9 @@ typedef struct tamgcn_f2_gcn_desc {
     const float* wd; const float* bd;                /* [Cout][Cin], [Cout] folded down conv + BatchNorm (res_mode 2) or NULL */
     float* E;                                        /* (N, S, Cout, V, V) */
     float* sum; float* diff;                         /* (N, Cout, T, V) each (not touched by _f2_e) */
+    const float* xpart;                              /* NULL | (N, ceil(T/4), Cin, V): the sums over each 4-frame tile of x that the
+                                                        previous block's _f2_tcn left (xpart there); _f2_e then takes mean_t(x) from
+                                                        them instead of reading x again */
 } tamgcn_f2_gcn_desc;
 int tamgcn_f2_e(const tamgcn_f2_gcn_desc* d, void* stream);
 int tamgcn_f2_gcn(const tamgcn_f2_gcn_desc* d, void* stream);
@@ -421,6 +424,7 @@ typedef struct tamgcn_f2_tcn_desc {
     const float* sp; const float* tp;
     const float* x; const float* wr; const float* br;
     float* out;
+    float* xpart;                                    /* NULL | (N, ceil(T_out/4), Cout, V): per-tile frame sums of out */
 } tamgcn_f2_tcn_desc;
 int tamgcn_f2_tcn(const tamgcn_f2_tcn_desc* d, void* stream);
 

@@ -69,7 +69,7 @@ class CtrgcDesc(C.Structure):
 class F2GcnDesc(C.Structure):
     _fields_ = [(k, C.c_int) for k in ('N', 'Cin', 'Cout', 'T', 'V', 'S', 'R', 'res_mode')] + \
                [(k, C.c_void_p) for k in ('x', 'w12', 'b12', 'w4', 'b4', 'A', 'alpha', 'w3', 'b3', 'sy', 'ty', 'wd', 'bd',
-                                          'E', 'sum', 'diff')]
+                                          'E', 'sum', 'diff', 'xpart')]
 
 
 class F2GemmDesc(C.Structure):
@@ -80,7 +80,7 @@ class F2GemmDesc(C.Structure):
 class F2TcnDesc(C.Structure):
     _fields_ = [(k, C.c_int) for k in ('N', 'Cin', 'Cout', 'T', 'V', 'stride', 'Cb', 'nb', 'ks', 'res_mode')] + \
                [('dil', C.c_int * 4), ('h', C.c_void_p), ('wt', C.c_void_p * 4), ('bt', C.c_void_p * 4)] + \
-               [(k, C.c_void_p) for k in ('sp', 'tp', 'x', 'wr', 'br', 'out')]
+               [(k, C.c_void_p) for k in ('sp', 'tp', 'x', 'wr', 'br', 'out', 'xpart')]
 
 
 # name -> (restype, argtypes); must list every symbol of include/tamgcn.h

@@ -43,22 +43,41 @@ __device__ __forceinline__ void f2_load_a(const float* arow, int K, int k0, int 
     }
 }
 
-// acc[ct] += A[16 rows][k blocks kb0, kb0 + kbstep, ...] * B, B value for this lane's column of tile ct at row k = bf(k, ct)
+// acc[ct] += A[16 rows][k blocks kb0, kb0 + kbstep, ...] * B, B value for this lane's column of tile ct at row k = bf(k, ct).
+// A fragments are fetched four blocks at a time, one group ahead: with one block in flight the loop was one L2 round trip
+// (~0.8 us) per 20 MFMAs (~0.1 us).
 template <int NCT, class BF>
 __device__ __forceinline__ void f2_gemm16(f32x4 (&acc)[NCT], const float* arow, int K, bool vec, int kb0, int kbstep, int kq, BF bf) {
+    constexpr int G = 4;
     const int nkb = (K + 15) >> 4;
-    float a[4], an[4] = {0.f, 0.f, 0.f, 0.f};
-    if (kb0 < nkb) f2_load_a(arow, K, kb0 * 16, kq, vec, a);
-    for (int kb = kb0; kb < nkb; kb += kbstep) {
-        if (kb + kbstep < nkb) f2_load_a(arow, K, (kb + kbstep) * 16, kq, vec, an);
+    float a[G][4], an[G][4];
+    auto loadg = [&](int kb, float (&dst)[G][4]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = kb * 16 + 4 * kq + i;
+        for (int g = 0; g < G; ++g) {
+            const int b = kb + g * kbstep;
+            if (b < nkb) f2_load_a(arow, K, b * 16, kq, vec, dst[g]);
+            else { dst[g][0] = dst[g][1] = dst[g][2] = dst[g][3] = 0.f; }
+        }
+    };
+    loadg(kb0, a);
+    for (int kb = kb0; kb < nkb; kb += G * kbstep) {
+        loadg(kb + G * kbstep, an);
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) acc[ct] = mfma16(a[i], bf(k, ct), acc[ct]);
+        for (int g = 0; g < G; ++g) {
+            const int b = kb + g * kbstep;
+            if (b < nkb) {                                         // wave-uniform: a whole block of 4 x NCT MFMAs
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k = b * 16 + 4 * kq + i;
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) acc[ct] = mfma16(a[g][i], bf(k, ct), acc[ct]);
+                }
+            }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = an[i];
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[g][i] = an[g][i];
     }
 }
 
@@ -88,7 +107,7 @@ __device__ __forceinline__ void f2_stage(float* Bs, const float* src, long long 
 // ---------------------------------------------------------------------------------------------------------------------
 struct F2GcnArgs {
     int N, Cin, Cout, T, S, R, res_mode;
-    const float *x, *w12, *b12, *w4, *b4, *A, *alpha, *w3, *b3, *sy, *ty, *wd, *bd;
+    const float *x, *w12, *b12, *w4, *b4, *A, *alpha, *w3, *b3, *sy, *ty, *wd, *bd, *xpart;
     float *E, *sum, *diff;
     int vec12, vec4, vec3, vecd;
 };
@@ -108,39 +127,62 @@ __global__ __launch_bounds__(F2_NT) void f2_e_kernel(const F2GcnArgs a) {
     const int s = blockIdx.x / nct, c0 = (blockIdx.x - s * nct) * 16, n = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kq = lane >> 4;
     const long long TV = (long long)a.T * V;
-    // 1. xbar: four frame phases in parallel, summed in a fixed order
+    // 1. xbar.  From the producer's per-tile column sums when it left them (f2_tcn: [N][tiles][Cin][V]; reading all of x
+    // again in each of these workgroups was 10-20 us of dependent round trips), else from x: four frame phases in parallel.
+    // Either way summed in a fixed order.
     {
         float* XP = Ds;
-        const float* xb = a.x + (long long)n * a.Cin * TV;
-        for (int e = tid; e < NTP * a.Cin * 5; e += NT) {
-            const int tp = e / (a.Cin * 5), rem = e - tp * a.Cin * 5;
-            const int ci = rem / 5, v4 = (rem - ci * 5) * 4;
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float* p = xb + ci * TV + v4;
-            for (int t = tp; t < a.T; t += 8 * NTP) {              // eight loads in flight, summed in frame order
-                float4 q[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    q[i] = t + i * NTP < a.T ? *reinterpret_cast<const float4*>(p + (long long)(t + i * NTP) * V) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { acc.x += q[i].x; acc.y += q[i].y; acc.z += q[i].z; acc.w += q[i].w; }
-            }
-            *reinterpret_cast<float4*>(XP + (tp * Kp + ci) * V + v4) = acc;
-        }
-        __syncthreads();
         const float inv = 1.f / (float)a.T;
-        for (int e = tid; e < Kp * (PX / 4); e += NT) {
-            const int ci = e / (PX / 4), v4 = (e - ci * (PX / 4)) * 4;
-            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ci < a.Cin && v4 < V) {
+        if (a.xpart) {
+            const int ntt = (a.T + F2_BT - 1) / F2_BT;
+            const float* xp = a.xpart + (long long)n * ntt * a.Cin * V;
+            for (int e = tid; e < Kp * (PX / 4); e += NT) {
+                const int ci = e / (PX / 4), v4 = (e - ci * (PX / 4)) * 4;
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ci < a.Cin && v4 < V) {
+                    for (int t0 = 0; t0 < ntt; t0 += 8) {
+                        float4 q[8];
 #pragma unroll
-                for (int tp = 0; tp < NTP; ++tp) {
-                    const float4 q = *reinterpret_cast<const float4*>(XP + (tp * Kp + ci) * V + v4);
-                    o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
+                        for (int i = 0; i < 8; ++i)
+                            q[i] = t0 + i < ntt ? *reinterpret_cast<const float4*>(xp + ((long long)(t0 + i) * a.Cin + ci) * V + v4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { o.x += q[i].x; o.y += q[i].y; o.z += q[i].z; o.w += q[i].w; }
+                    }
+                    o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
                 }
-                o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
+                *reinterpret_cast<float4*>(XB + ci * PX + v4) = o;
             }
-            *reinterpret_cast<float4*>(XB + ci * PX + v4) = o;
+        } else {
+            const float* xb = a.x + (long long)n * a.Cin * TV;
+            for (int e = tid; e < NTP * a.Cin * 5; e += NT) {
+                const int tp = e / (a.Cin * 5), rem = e - tp * a.Cin * 5;
+                const int ci = rem / 5, v4 = (rem - ci * 5) * 4;
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float* p = xb + ci * TV + v4;
+                for (int t = tp; t < a.T; t += 8 * NTP) {              // eight loads in flight, summed in frame order
+                    float4 q[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        q[i] = t + i * NTP < a.T ? *reinterpret_cast<const float4*>(p + (long long)(t + i * NTP) * V) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { acc.x += q[i].x; acc.y += q[i].y; acc.z += q[i].z; acc.w += q[i].w; }
+                }
+                *reinterpret_cast<float4*>(XP + (tp * Kp + ci) * V + v4) = acc;
+            }
+            __syncthreads();
+            for (int e = tid; e < Kp * (PX / 4); e += NT) {
+                const int ci = e / (PX / 4), v4 = (e - ci * (PX / 4)) * 4;
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ci < a.Cin && v4 < V) {
+#pragma unroll
+                    for (int tp = 0; tp < NTP; ++tp) {
+                        const float4 q = *reinterpret_cast<const float4*>(XP + (tp * Kp + ci) * V + v4);
+                        o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
+                    }
+                    o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
+                }
+                *reinterpret_cast<float4*>(XB + ci * PX + v4) = o;
+            }
         }
         __syncthreads();
     }
@@ -166,6 +208,16 @@ __global__ __launch_bounds__(F2_NT) void f2_e_kernel(const F2GcnArgs a) {
         }
         __syncthreads();
     }
+    // (the E product's weight fragments travel under the tanh pass)
+    const float alpha = a.alpha[0];
+    float aw[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, b4r[4];
+    {
+        const float* arow = a.w4 + ((long long)s * a.Cout + c0 + j) * a.R;
+        f2_load_a(arow, a.R, 0, kq, a.vec4 != 0, aw[0]);
+        if (a.R > 16) f2_load_a(arow, a.R, 16, kq, a.vec4 != 0, aw[1]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b4r[r] = a.b4[s * a.Cout + c0 + kq * 4 + r];
+    }
     // 3. D[r][u*V + v] = tanh(p[r][u] - q[r][v]); rows R..Rp zero
     for (int e = tid; e < Rp * VV; e += NT) {
         const int r = e / VV, uv = e - r * VV;
@@ -175,14 +227,6 @@ __global__ __launch_bounds__(F2_NT) void f2_e_kernel(const F2GcnArgs a) {
     __syncthreads();
     // 4. E tile = alpha (W4 D + b4) + A: 16 channels x 400, 25 column tiles over the four waves, K = R <= 32
     {
-        const float alpha = a.alpha[0];
-        const float* arow = a.w4 + ((long long)s * a.Cout + c0 + j) * a.R;
-        float aw[2][4];
-        f2_load_a(arow, a.R, 0, kq, a.vec4 != 0, aw[0]);
-        if (a.R > 16) f2_load_a(arow, a.R, 16, kq, a.vec4 != 0, aw[1]);
-        float b4r[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) b4r[r] = a.b4[s * a.Cout + c0 + kq * 4 + r];
         float* Eg = a.E + (((long long)n * a.S + s) * a.Cout + c0) * VV;
         for (int ct = wave; ct < VV / 16; ct += 4) {
             const int col = ct * 16 + j;
@@ -353,6 +397,7 @@ struct F2TcnArgs {
     const float *sp, *tp;                // pooled branch's BatchNorm as an affine [Cb]
     const float *x, *wr, *br;            // block input (N, Cin, T, V); folded residual conv [Cout][Cin], [Cout]
     float* out;                          // (N, Cout, T2, V)
+    float* xpart;                        // NULL | (N, ceil(T2 / 4), Cout, V): sum over each tile's frames of out (the next block's xbar)
 };
 
 constexpr int F2_HF = 15, F2_PH = F2_HF * F2_V + 4;    // halo tile: 3*stride + (ks-1)*dil + 1 <= 15 frames
@@ -362,7 +407,8 @@ __global__ __launch_bounds__(F2_NT) void f2_tcn_kernel(const F2TcnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Kp = a.res_mode == 2 ? (a.Cin + 15) & ~15 : 0;
     float* Pp = smem;                    // [4][16][PB]
-    float* Xs = Pp + 4 * 16 * PB;        // [Kp][PB]      strided frames of the block input (convolutional residual)
+    float* Ot = Pp + 4 * 16 * PB;        // [16][PB]      finished tile (for the column sums)
+    float* Xs = Ot + 16 * PB;            // [Kp][PB]      strided frames of the block input (convolutional residual)
     float* Hs = Xs + Kp * PB;            // [Cb][PH]      this branch's entry output with the temporal halo
     const int nmt = a.Cout / 16;
     const int mtile = blockIdx.x % nmt, tt = blockIdx.x / nmt, n = blockIdx.y;
@@ -475,6 +521,20 @@ __global__ __launch_bounds__(F2_NT) void f2_tcn_kernel(const F2TcnArgs a) {
         }
         float4 r = make_float4(fmaxf(val[0], 0.f), fmaxf(val[1], 0.f), fmaxf(val[2], 0.f), fmaxf(val[3], 0.f));
         *reinterpret_cast<float4*>(a.out + ((long long)n * a.Cout + c) * TV2 + (long long)tq * V + v) = r;
+        *reinterpret_cast<float4*>(Ot + row * PB + c4) = r;
+    }
+    if (a.xpart) {
+        __syncthreads();
+        if (tid < 16 * 5) {
+            const int row = tid / 5, v4 = (tid - row * 5) * 4;
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int tl = 0; tl < bt; ++tl) {
+                const float4 q = *reinterpret_cast<const float4*>(Ot + row * PB + tl * V + v4);
+                o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
+            }
+            const int ntt = (a.T2 + F2_BT - 1) / F2_BT;
+            *reinterpret_cast<float4*>(a.xpart + (((long long)n * ntt + tt) * a.Cout + c0 + row) * V + v4) = o;
+        }
     }
 }
 
@@ -488,7 +548,7 @@ size_t f2_e_lds(int Cin, int R) {
 size_t f2_gcn_lds(int Cin) { return sizeof(float) * ((size_t)((Cin + 15) & ~15) * F2_PB + 2 * 32 * F2_PB + 3 * F2_ES); }
 size_t f2_gemm_lds(int K) { return sizeof(float) * ((size_t)((K + 15) & ~15) * F2_PB + 4 * 16 * F2_PB); }
 size_t f2_tcn_lds(int Cin, int Cb, int res_mode) {
-    return sizeof(float) * ((size_t)4 * 16 * F2_PB + (size_t)(res_mode == 2 ? (Cin + 15) & ~15 : 0) * F2_PB + (size_t)Cb * F2_PH);
+    return sizeof(float) * ((size_t)5 * 16 * F2_PB + (size_t)(res_mode == 2 ? (Cin + 15) & ~15 : 0) * F2_PB + (size_t)Cb * F2_PH);
 }
 
 int f2_fill(const tamgcn_f2_gcn_desc* d, F2GcnArgs* a, const char* who) {
@@ -501,11 +561,11 @@ int f2_fill(const tamgcn_f2_gcn_desc* d, F2GcnArgs* a, const char* who) {
     TG_CHECK(d->res_mode >= 0 && d->res_mode <= 2, "%s: res_mode=%d", who, d->res_mode);
     TG_CHECK(d->res_mode != 1 || d->Cin == d->Cout, "%s: identity residual needs Cin == Cout", who);
     TG_CHECK(d->res_mode != 2 || (d->wd && d->bd), "%s: convolutional residual without weights", who);
-    TG_CHECK(al16(d->x) && al16(d->E), "%s: x and E must be 16-byte aligned", who);
+    TG_CHECK(al16(d->x) && al16(d->E) && (!d->xpart || al16(d->xpart)), "%s: x, E and xpart must be 16-byte aligned", who);
     a->N = d->N; a->Cin = d->Cin; a->Cout = d->Cout; a->T = d->T; a->S = d->S; a->R = d->R; a->res_mode = d->res_mode;
     a->x = d->x; a->w12 = d->w12; a->b12 = d->b12; a->w4 = d->w4; a->b4 = d->b4; a->A = d->A; a->alpha = d->alpha;
     a->w3 = d->w3; a->b3 = d->b3; a->sy = d->sy; a->ty = d->ty; a->wd = d->wd; a->bd = d->bd;
-    a->E = d->E; a->sum = d->sum; a->diff = d->diff;
+    a->E = d->E; a->sum = d->sum; a->diff = d->diff; a->xpart = d->xpart;
     a->vec12 = d->Cin % 16 == 0 && al16(d->w12);
     a->vec3 = d->Cin % 16 == 0 && al16(d->w3);
     a->vecd = d->res_mode == 2 && d->Cin % 16 == 0 && al16(d->wd);
@@ -577,7 +637,7 @@ extern "C" int tamgcn_f2_tcn(const tamgcn_f2_tcn_desc* d, void* stream) {
     TG_CHECK(d->res_mode == 0 || d->x, "tamgcn_f2_tcn: residual without the block input");
     TG_CHECK(d->res_mode != 1 || (d->Cin == d->Cout && d->stride == 1), "tamgcn_f2_tcn: identity residual needs Cin == Cout, stride 1");
     TG_CHECK(d->res_mode != 2 || (d->wr && d->br && d->Cin > 0 && d->Cin <= 256), "tamgcn_f2_tcn: convolutional residual: weights / Cin=%d", d->Cin);
-    TG_CHECK(al16(d->h) && al16(d->out) && (!d->x || al16(d->x)), "tamgcn_f2_tcn: activations must be 16-byte aligned");
+    TG_CHECK(al16(d->h) && al16(d->out) && (!d->x || al16(d->x)) && (!d->xpart || al16(d->xpart)), "tamgcn_f2_tcn: activations must be 16-byte aligned");
     F2TcnArgs a;
     a.N = d->N; a.Cin = d->Cin; a.Cout = d->Cout; a.T = d->T; a.stride = d->stride; a.T2 = (d->T - 1) / d->stride + 1;
     a.Cb = d->Cb; a.nb = d->nb; a.ks = d->ks; a.res_mode = d->res_mode;
@@ -590,7 +650,7 @@ extern "C" int tamgcn_f2_tcn(const tamgcn_f2_tcn_desc* d, void* stream) {
     }
     a.vect = vt;
     a.vecr = d->res_mode == 2 && d->Cin % 16 == 0 && al16(d->wr);
-    a.h = d->h; a.sp = d->sp; a.tp = d->tp; a.x = d->x; a.wr = d->wr; a.br = d->br; a.out = d->out;
+    a.h = d->h; a.sp = d->sp; a.tp = d->tp; a.x = d->x; a.wr = d->wr; a.br = d->br; a.out = d->out; a.xpart = d->xpart;
     const size_t lds = f2_tcn_lds(d->Cin, d->Cb, d->res_mode);
     TG_CHECK(lds <= 160 * 1024, "tamgcn_f2_tcn: %zu bytes of LDS", lds);
     static tg_devmask flag = 0;

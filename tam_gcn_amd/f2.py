@@ -132,7 +132,7 @@ class FusedEval:
         return self._blocks
 
     # ---- one block ---------------------------------------------------------------------------------------------------
-    def _block(self, b, x, st):
+    def _block(self, b, x, st, xpart=None, want_xpart=False):
         lib = self.lib
         N, Cin, T, V = x.shape
         Cout = b.Cout
@@ -144,7 +144,7 @@ class FusedEval:
                            x=x.data_ptr(), w12=b.W12.data_ptr(), b12=b.B12.data_ptr(), w4=b.W4.data_ptr(), b4=b.B4.data_ptr(),
                            A=b.PA.data_ptr(), alpha=b.alpha.data_ptr(), w3=b.W3.data_ptr(), b3=b.B3.data_ptr(),
                            sy=b.sy.data_ptr(), ty=b.ty.data_ptr(), wd=_ptr(b.Wd), bd=_ptr(b.bd),
-                           E=E.data_ptr(), sum=sm.data_ptr(), diff=df.data_ptr())
+                           E=E.data_ptr(), sum=sm.data_ptr(), diff=df.data_ptr(), xpart=_ptr(xpart))
         _lib.check(lib.tamgcn_f2_e(C.byref(d), st), 'tamgcn_f2_e')
         _lib.check(lib.tamgcn_f2_gcn(C.byref(d), st), 'tamgcn_f2_gcn')
         q = _lib.F2GemmDesc(N=N, K=Cout, M=Cout, T=T, V=V, mode=0, relu_rows=0, x=df.data_ptr(), w=b.Wo.data_ptr(), b=b.bo.data_ptr(),
@@ -155,15 +155,16 @@ class FusedEval:
         _lib.check(lib.tamgcn_f2_gemm(C.byref(q), st), 'tamgcn_f2_gemm')
         T2 = (T - 1) // b.stride + 1
         out = torch.empty(N, Cout, T2, V, device=dev)
+        xp = torch.empty(N, (T2 + 3) // 4, Cout, V, device=dev) if want_xpart else None     # per-tile frame sums: the next block's xbar
         t = _lib.F2TcnDesc(N=N, Cin=b.Cres, Cout=Cout, T=T, V=V, stride=b.stride, Cb=b.Cb, nb=b.nb, ks=b.ks, res_mode=b.rmode,
                            h=h.data_ptr(), sp=b.sp.data_ptr(), tp=b.tp.data_ptr(), x=x.data_ptr(), wr=_ptr(b.Wr), br=_ptr(b.br),
-                           out=out.data_ptr())
+                           out=out.data_ptr(), xpart=_ptr(xp))
         for i in range(b.nb):
             t.dil[i] = b.dils[i]
             t.wt[i] = b.Wt[i].data_ptr()
             t.bt[i] = b.bt[i].data_ptr()
         _lib.check(lib.tamgcn_f2_tcn(C.byref(t), st), 'tamgcn_f2_tcn')
-        return out
+        return (out, xp) if want_xpart else out
 
     # ---- the model ---------------------------------------------------------------------------------------------------
     def blocks(self, x):
@@ -184,8 +185,9 @@ class FusedEval:
         blocks = self._packed(x.device)
         st = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
         h = Fn.StemFn.run(m.data_bn, x.contiguous(), m.data_bn.weight, m.data_bn.bias)
-        for b in blocks:
-            h = self._block(b, h, st)
+        xp = None
+        for i, b in enumerate(blocks):
+            h, xp = self._block(b, h, st, xpart=xp, want_xpart=True)
         return h, N, M
 
     def __call__(self, x):
