@@ -46,22 +46,25 @@ __device__ __forceinline__ void f2_load_a(const float* arow, int K, int k0, int 
 // acc[ct] += A[16 rows][k blocks kb0, kb0 + kbstep, ...] * B, B value for this lane's column of tile ct at row k = bf(k, ct).
 // A fragments are fetched four blocks at a time, one group ahead: with one block in flight the loop was one L2 round trip
 // (~0.8 us) per 20 MFMAs (~0.1 us).
-template <int NCT, class BF>
-__device__ __forceinline__ void f2_gemm16(f32x4 (&acc)[NCT], const float* arow, int K, bool vec, int kb0, int kbstep, int kq, BF bf) {
-    constexpr int G = 4;
+constexpr int F2_G = 4;
+__device__ __forceinline__ void f2_load_group(const float* arow, int K, bool vec, int kb, int kbstep, int kq, float (&dst)[F2_G][4]) {
     const int nkb = (K + 15) >> 4;
-    float a[G][4], an[G][4];
-    auto loadg = [&](int kb, float (&dst)[G][4]) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const int b = kb + g * kbstep;
-            if (b < nkb) f2_load_a(arow, K, b * 16, kq, vec, dst[g]);
-            else { dst[g][0] = dst[g][1] = dst[g][2] = dst[g][3] = 0.f; }
-        }
-    };
-    loadg(kb0, a);
+    for (int g = 0; g < F2_G; ++g) {
+        const int b = kb + g * kbstep;
+        if (b < nkb) f2_load_a(arow, K, b * 16, kq, vec, dst[g]);
+        else { dst[g][0] = dst[g][1] = dst[g][2] = dst[g][3] = 0.f; }
+    }
+}
+
+// a: the first group (blocks kb0, kb0 + kbstep, ...), already requested by the caller -- before whatever B waits for
+template <int NCT, class BF>
+__device__ __forceinline__ void f2_gemm16_pre(f32x4 (&acc)[NCT], float (&a)[F2_G][4], const float* arow, int K, bool vec, int kb0, int kbstep, int kq, BF bf) {
+    constexpr int G = F2_G;
+    const int nkb = (K + 15) >> 4;
+    float an[G][4];
     for (int kb = kb0; kb < nkb; kb += G * kbstep) {
-        loadg(kb + G * kbstep, an);
+        f2_load_group(arow, K, vec, kb + G * kbstep, kbstep, kq, an);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int b = kb + g * kbstep;
@@ -79,6 +82,13 @@ __device__ __forceinline__ void f2_gemm16(f32x4 (&acc)[NCT], const float* arow, 
 #pragma unroll
             for (int i = 0; i < 4; ++i) a[g][i] = an[g][i];
     }
+}
+
+template <int NCT, class BF>
+__device__ __forceinline__ void f2_gemm16(f32x4 (&acc)[NCT], const float* arow, int K, bool vec, int kb0, int kbstep, int kq, BF bf) {
+    float a[F2_G][4];
+    f2_load_group(arow, K, vec, kb0, kbstep, kq, a);
+    f2_gemm16_pre<NCT>(acc, a, arow, K, vec, kb0, kbstep, kq, bf);
 }
 
 // rows [0, K) of a (rows, T, V) activation, frames t0 + tl*fstep (tl < bt), as an LDS tile [Kp][F2_PB]; everything else zero
@@ -127,6 +137,27 @@ __global__ __launch_bounds__(F2_NT) void f2_e_kernel(const F2GcnArgs a) {
     const int s = blockIdx.x / nct, c0 = (blockIdx.x - s * nct) * 16, n = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kq = lane >> 4;
     const long long TV = (long long)a.T * V;
+    // Everything that does not depend on x is requested now and used after the xbar phase: the kernel is a chain of dependent
+    // round trips on 12..48 workgroups, not a bandwidth problem
+    const int nrt = R2p / 16, nparts = 4 / nrt;                // pq product: 1 x 4, 2 x 2 or 4 x 1 (row tiles x K parts) over the waves
+    const int prt = wave % nrt, ppart = wave / nrt;
+    const float* a12 = prt * 16 + j < R2 ? a.w12 + ((long long)s * R2 + prt * 16 + j) * a.Cin : nullptr;
+    float a12g[F2_G][4];
+    f2_load_group(a12, a.Cin, a.vec12 != 0, ppart, nparts, kq, a12g);
+    float b12r[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) b12r[i] = tid + i * NT < R2 * V ? a.b12[s * R2 + (tid + i * NT) / V] : 0.f;
+    const float alpha = a.alpha[0];
+    float aw[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, b4r[4], Avr[7];
+    {
+        const float* arow = a.w4 + ((long long)s * a.Cout + c0 + j) * a.R;
+        f2_load_a(arow, a.R, 0, kq, a.vec4 != 0, aw[0]);
+        if (a.R > 16) f2_load_a(arow, a.R, 16, kq, a.vec4 != 0, aw[1]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b4r[r] = a.b4[s * a.Cout + c0 + kq * 4 + r];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) Avr[i] = wave + 4 * i < VV / 16 ? a.A[s * VV + (wave + 4 * i) * 16 + j] : 0.f;
+    }
     // 1. xbar.  From the producer's per-tile column sums when it left them (f2_tcn: [N][tiles][Cin][V]; reading all of x
     // again in each of these workgroups was 10-20 us of dependent round trips), else from x: four frame phases in parallel.
     // Either way summed in a fixed order.
@@ -134,23 +165,38 @@ __global__ __launch_bounds__(F2_NT) void f2_e_kernel(const F2GcnArgs a) {
         float* XP = Ds;
         const float inv = 1.f / (float)a.T;
         if (a.xpart) {
-            const int ntt = (a.T + F2_BT - 1) / F2_BT;
+            // (tile group g, channel, joint quad): NTP groups of tpg tiles each; eight such sums advance together, one tile (= one
+            // load each, eight in flight) per step
+            const int ntt = (a.T + F2_BT - 1) / F2_BT, tpg = (ntt + NTP - 1) / NTP;
             const float* xp = a.xpart + (long long)n * ntt * a.Cin * V;
-            for (int e = tid; e < Kp * (PX / 4); e += NT) {
-                const int ci = e / (PX / 4), v4 = (e - ci * (PX / 4)) * 4;
-                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ci < a.Cin && v4 < V) {
-                    for (int t0 = 0; t0 < ntt; t0 += 8) {
-                        float4 q[8];
+            const int cnt = NTP * a.Cin * 5;
+            for (int e0 = tid; e0 < cnt; e0 += 8 * NT) {
+                float4 acc[8];
+                int off[8], g8[8];
 #pragma unroll
-                        for (int i = 0; i < 8; ++i)
-                            q[i] = t0 + i < ntt ? *reinterpret_cast<const float4*>(xp + ((long long)(t0 + i) * a.Cin + ci) * V + v4) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) { o.x += q[i].x; o.y += q[i].y; o.z += q[i].z; o.w += q[i].w; }
-                    }
-                    o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
+                for (int p = 0; p < 8; ++p) {
+                    const int e = e0 + p * NT;
+                    const int g = e / (a.Cin * 5), rem = e - g * a.Cin * 5;
+                    const int ci = rem / 5, v4 = (rem - ci * 5) * 4;
+                    acc[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    off[p] = ci * V + v4;
+                    g8[p] = e < cnt ? g : NTP;                      // NTP * tpg >= ntt: an out-of-range pair never loads
                 }
-                *reinterpret_cast<float4*>(XB + ci * PX + v4) = o;
+                for (int i = 0; i < tpg; ++i) {
+                    float4 q[8];
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) {
+                        const int tile = g8[p] * tpg + i;
+                        q[p] = tile < ntt ? *reinterpret_cast<const float4*>(xp + (long long)tile * a.Cin * V + off[p]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) { acc[p].x += q[p].x; acc[p].y += q[p].y; acc[p].z += q[p].z; acc[p].w += q[p].w; }
+                }
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    const int e = e0 + p * NT;
+                    if (e < cnt) *reinterpret_cast<float4*>(XP + (g8[p] * Kp) * V + off[p]) = acc[p];
+                }
             }
         } else {
             const float* xb = a.x + (long long)n * a.Cin * TV;
@@ -169,7 +215,9 @@ __global__ __launch_bounds__(F2_NT) void f2_e_kernel(const F2GcnArgs a) {
                 }
                 *reinterpret_cast<float4*>(XP + (tp * Kp + ci) * V + v4) = acc;
             }
-            __syncthreads();
+        }
+        __syncthreads();
+        {
             for (int e = tid; e < Kp * (PX / 4); e += NT) {
                 const int ci = e / (PX / 4), v4 = (e - ci * (PX / 4)) * 4;
                 float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -186,37 +234,27 @@ __global__ __launch_bounds__(F2_NT) void f2_e_kernel(const F2GcnArgs a) {
         }
         __syncthreads();
     }
-    // 2. p, q = W12_s xbar + b12_s: (2R x Cin) x (Cin x 20); row tiles x K parts over the four waves
+    // 2. p, q = W12_s xbar + b12_s: (2R x Cin) x (Cin x 20)
     {
-        const int nrt = R2p / 16, nparts = 4 / nrt;            // 1 x 4, 2 x 2 or 4 x 1
-        const int rt = wave % nrt, part = wave / nrt;
-        const int row = rt * 16 + j;
-        const float* arow = row < R2 ? a.w12 + ((long long)s * R2 + row) * a.Cin : nullptr;
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        f2_gemm16<2>(acc, arow, a.Cin, a.vec12 != 0, part, nparts, kq, [&](int k, int ct) { return XB[k * PX + ct * 16 + j]; });
+        f2_gemm16_pre<2>(acc, a12g, a12, a.Cin, a.vec12 != 0, ppart, nparts, kq, [&](int k, int ct) { return XB[k * PX + ct * 16 + j]; });
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Pp[((part * nrt + rt) * 16 + kq * 4 + r) * PX + ct * 16 + j] = acc[ct][r];
+            for (int r = 0; r < 4; ++r) Pp[((ppart * nrt + prt) * 16 + kq * 4 + r) * PX + ct * 16 + j] = acc[ct][r];
         __syncthreads();
-        for (int e = tid; e < R2 * V; e += NT) {
-            const int row2 = e / V, v = e - row2 * V;
-            const int rt2 = row2 >> 4, rr = row2 & 15;
-            float t = a.b12[s * R2 + row2];
-            for (int p = 0; p < nparts; ++p) t += Pp[((p * nrt + rt2) * 16 + rr) * PX + v];
-            PQ[row2 * PX + v] = t;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int e = tid + i * NT;
+            if (e < R2 * V) {
+                const int row2 = e / V, v = e - row2 * V;
+                const int rt2 = row2 >> 4, rr = row2 & 15;
+                float t = b12r[i];
+                for (int p = 0; p < nparts; ++p) t += Pp[((p * nrt + rt2) * 16 + rr) * PX + v];
+                PQ[row2 * PX + v] = t;
+            }
         }
         __syncthreads();
-    }
-    // (the E product's weight fragments travel under the tanh pass)
-    const float alpha = a.alpha[0];
-    float aw[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, b4r[4];
-    {
-        const float* arow = a.w4 + ((long long)s * a.Cout + c0 + j) * a.R;
-        f2_load_a(arow, a.R, 0, kq, a.vec4 != 0, aw[0]);
-        if (a.R > 16) f2_load_a(arow, a.R, 16, kq, a.vec4 != 0, aw[1]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) b4r[r] = a.b4[s * a.Cout + c0 + kq * 4 + r];
     }
     // 3. D[r][u*V + v] = tanh(p[r][u] - q[r][v]); rows R..Rp zero
     for (int e = tid; e < Rp * VV; e += NT) {
@@ -228,18 +266,21 @@ __global__ __launch_bounds__(F2_NT) void f2_e_kernel(const F2GcnArgs a) {
     // 4. E tile = alpha (W4 D + b4) + A: 16 channels x 400, 25 column tiles over the four waves, K = R <= 32
     {
         float* Eg = a.E + (((long long)n * a.S + s) * a.Cout + c0) * VV;
-        for (int ct = wave; ct < VV / 16; ct += 4) {
-            const int col = ct * 16 + j;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc = mfma16(aw[0][i], Ds[(4 * kq + i) * PD + col], acc);
-            if (a.R > 16) {
+        for (int it = 0; it < 7; ++it) {
+            const int ct = wave + 4 * it;
+            if (ct < VV / 16) {
+                const int col = ct * 16 + j;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc = mfma16(aw[1][i], Ds[(16 + 4 * kq + i) * PD + col], acc);
+                for (int i = 0; i < 4; ++i) acc = mfma16(aw[0][i], Ds[(4 * kq + i) * PD + col], acc);
+                if (a.R > 16) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc = mfma16(aw[1][i], Ds[(16 + 4 * kq + i) * PD + col], acc);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Eg[(long long)(kq * 4 + r) * VV + col] = alpha * (acc[r] + b4r[r]) + Avr[it];
             }
-            const float Av = a.A[s * VV + col];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Eg[(long long)(kq * 4 + r) * VV + col] = alpha * (acc[r] + b4r[r]) + Av;
         }
     }
 }
@@ -267,18 +308,24 @@ __global__ __launch_bounds__(F2_NT) void f2_gcn_kernel(const F2GcnArgs a) {
         const float* g = a.E + (((long long)n * a.S + s) * a.Cout + c0) * VV + f;
         __builtin_amdgcn_global_load_lds((f2_gptr)g, (f2_lptr)(Es + s * ES + q * 256), 16, 0, 0);
     }
+    const int rt = wave & 1, kh = wave >> 1;
+    const float* arow;
+    bool vec;
+    {
+        const int row = rt * 16 + j, sidx = row >> 3, c = row & 7;
+        arow = sidx < 3 ? a.w3 + ((long long)sidx * a.Cout + c0 + c) * a.Cin
+                        : (a.res_mode == 2 ? a.wd + (long long)(c0 + c) * a.Cin : nullptr);
+        vec = sidx < 3 ? a.vec3 != 0 : a.vecd != 0;               // (uniform per 8 lanes, both paths are branch-safe)
+    }
+    float ag[F2_G][4];
+    f2_load_group(arow, a.Cin, vec, kh, 2, kq, ag);                // weights travel under the staging of the tile
     f2_stage(Xs, a.x + (long long)n * a.Cin * TV + (long long)t0 * V, TV, a.Cin, Kp, bt, 1, tid);
     __syncthreads();
     {
-        const int rt = wave & 1, kh = wave >> 1;
-        const int row = rt * 16 + j, sidx = row >> 3, c = row & 7;
-        const float* arow = sidx < 3 ? a.w3 + ((long long)sidx * a.Cout + c0 + c) * a.Cin
-                                     : (a.res_mode == 2 ? a.wd + (long long)(c0 + c) * a.Cin : nullptr);
-        const bool vec = sidx < 3 ? a.vec3 != 0 : a.vecd != 0;    // (uniform per 8 lanes, both paths are branch-safe)
         f32x4 acc[F2_NCT];
 #pragma unroll
         for (int ct = 0; ct < F2_NCT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        f2_gemm16<F2_NCT>(acc, arow, a.Cin, vec, kh, 2, kq, [&](int k, int ct) { return Xs[k * PB + ct * 16 + j]; });
+        f2_gemm16_pre<F2_NCT>(acc, ag, arow, a.Cin, vec, kh, 2, kq, [&](int k, int ct) { return Xs[k * PB + ct * 16 + j]; });
 #pragma unroll
         for (int ct = 0; ct < F2_NCT; ++ct)
 #pragma unroll
@@ -348,14 +395,16 @@ __global__ __launch_bounds__(F2_NT) void f2_gemm_kernel(const F2GemmArgs a) {
     const int m0 = mtile * 16, t0 = tt * F2_BT, bt = min(F2_BT, a.T - t0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kq = lane >> 4;
     const long long TV = (long long)a.T * V;
+    const float* arow = a.w + (long long)(m0 + j) * a.K;
+    float ag[F2_G][4];
+    f2_load_group(arow, a.K, a.vec != 0, wave, 4, kq, ag);         // weights travel under the staging of the tile
     f2_stage(Bs, a.x + (long long)n * a.K * TV + (long long)t0 * V, TV, a.K, Kp, bt, 1, tid);
     __syncthreads();
     {
         f32x4 acc[F2_NCT];
 #pragma unroll
         for (int ct = 0; ct < F2_NCT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        f2_gemm16<F2_NCT>(acc, a.w + (long long)(m0 + j) * a.K, a.K, a.vec != 0, wave, 4, kq,
-                          [&](int k, int ct) { return Bs[k * PB + ct * 16 + j]; });
+        f2_gemm16_pre<F2_NCT>(acc, ag, arow, a.K, a.vec != 0, wave, 4, kq, [&](int k, int ct) { return Bs[k * PB + ct * 16 + j]; });
 #pragma unroll
         for (int ct = 0; ct < F2_NCT; ++ct)
 #pragma unroll

@@ -18,8 +18,10 @@ There is no CPU path and no fallback inside: unsupported geometry raises `Unsupp
 caller (Model.forward) then takes the general eval path."""
 import ctypes as C
 import os
+from typing import List, Optional, Tuple
 
 import torch
+from torch import Tensor
 
 from . import _lib
 from . import functional as Fn
@@ -95,9 +97,14 @@ class _Block:
         self.Wr = self.br = None
         if Q.rmode == 'conv':
             self.Wr, self.br = _fold(Q.Wr.reshape(Q.Cout, -1), Q.br, Q.bnr)
-            self.Cres = self.Wr.shape[1]
-        else:
-            self.Cres = P.Cin
+        # the registered op's arguments: tensors in PARAMS order (an absent one is an empty tensor), geometry as integers
+        none = self.sy.new_empty(0)
+        self.params = [self.W12, self.B12, self.W3, self.B3, self.W4, self.B4, self.PA, self.alpha, self.sy, self.ty,
+                       none if self.Wd is None else self.Wd, none if self.bd is None else self.bd, self.Wo, self.bo, self.We, self.be,
+                       self.sp, self.tp, none if self.Wr is None else self.Wr, none if self.br is None else self.br]
+        for w, bb in zip(self.Wt, self.bt):
+            self.params += [w, bb]
+        self.geom = [self.R, self.gmode, self.Cb, self.nb, self.ks, self.stride, self.rmode] + self.dils
 
 
 def _ptr(t):
@@ -132,38 +139,8 @@ class FusedEval:
         return self._blocks
 
     # ---- one block ---------------------------------------------------------------------------------------------------
-    def _block(self, b, x, st, xpart=None, want_xpart=False):
-        lib = self.lib
-        N, Cin, T, V = x.shape
-        Cout = b.Cout
-        dev = x.device
-        E = torch.empty(N, 3, Cout, V, V, device=dev)
-        ws = torch.empty(4, N, Cout, T, V, device=dev)           # y + res, res - y, g, h
-        sm, df, g, h = ws[0], ws[1], ws[2], ws[3]
-        d = _lib.F2GcnDesc(N=N, Cin=Cin, Cout=Cout, T=T, V=V, S=3, R=b.R, res_mode=b.gmode,
-                           x=x.data_ptr(), w12=b.W12.data_ptr(), b12=b.B12.data_ptr(), w4=b.W4.data_ptr(), b4=b.B4.data_ptr(),
-                           A=b.PA.data_ptr(), alpha=b.alpha.data_ptr(), w3=b.W3.data_ptr(), b3=b.B3.data_ptr(),
-                           sy=b.sy.data_ptr(), ty=b.ty.data_ptr(), wd=_ptr(b.Wd), bd=_ptr(b.bd),
-                           E=E.data_ptr(), sum=sm.data_ptr(), diff=df.data_ptr(), xpart=_ptr(xpart))
-        _lib.check(lib.tamgcn_f2_e(C.byref(d), st), 'tamgcn_f2_e')
-        _lib.check(lib.tamgcn_f2_gcn(C.byref(d), st), 'tamgcn_f2_gcn')
-        q = _lib.F2GemmDesc(N=N, K=Cout, M=Cout, T=T, V=V, mode=0, relu_rows=0, x=df.data_ptr(), w=b.Wo.data_ptr(), b=b.bo.data_ptr(),
-                            add=sm.data_ptr(), out=g.data_ptr())
-        _lib.check(lib.tamgcn_f2_gemm(C.byref(q), st), 'tamgcn_f2_gemm')
-        q = _lib.F2GemmDesc(N=N, K=Cout, M=Cout, T=T, V=V, mode=1, relu_rows=(b.nb + 1) * b.Cb, x=g.data_ptr(), w=b.We.data_ptr(),
-                            b=b.be.data_ptr(), add=None, out=h.data_ptr())
-        _lib.check(lib.tamgcn_f2_gemm(C.byref(q), st), 'tamgcn_f2_gemm')
-        T2 = (T - 1) // b.stride + 1
-        out = torch.empty(N, Cout, T2, V, device=dev)
-        xp = torch.empty(N, (T2 + 3) // 4, Cout, V, device=dev) if want_xpart else None     # per-tile frame sums: the next block's xbar
-        t = _lib.F2TcnDesc(N=N, Cin=b.Cres, Cout=Cout, T=T, V=V, stride=b.stride, Cb=b.Cb, nb=b.nb, ks=b.ks, res_mode=b.rmode,
-                           h=h.data_ptr(), sp=b.sp.data_ptr(), tp=b.tp.data_ptr(), x=x.data_ptr(), wr=_ptr(b.Wr), br=_ptr(b.br),
-                           out=out.data_ptr(), xpart=_ptr(xp))
-        for i in range(b.nb):
-            t.dil[i] = b.dils[i]
-            t.wt[i] = b.Wt[i].data_ptr()
-            t.bt[i] = b.bt[i].data_ptr()
-        _lib.check(lib.tamgcn_f2_tcn(C.byref(t), st), 'tamgcn_f2_tcn')
+    def _block(self, b, x, st=None, xpart=None, want_xpart=False):
+        out, xp = torch.ops.tamgcn.tcn_gcn_unit_eval(x, xpart, b.params, b.geom)
         return (out, xp) if want_xpart else out
 
     # ---- the model ---------------------------------------------------------------------------------------------------
@@ -183,11 +160,10 @@ class FusedEval:
         if V != 20:
             raise Unsupported(f'{V} joints')
         blocks = self._packed(x.device)
-        st = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
         h = Fn.StemFn.run(m.data_bn, x.contiguous(), m.data_bn.weight, m.data_bn.bias)
         xp = None
         for i, b in enumerate(blocks):
-            h, xp = self._block(b, h, st, xpart=xp, want_xpart=True)
+            h, xp = self._block(b, h, xpart=xp, want_xpart=True)
         return h, N, M
 
     def __call__(self, x):
@@ -198,3 +174,68 @@ class FusedEval:
         return torch.ops.tamgcn.head(h, m.fc.weight, m.fc.bias, M)
 
     forward = __call__
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The block as a registered operator (BASELINE.json north_star: "registering custom ops through a thin C-ABI"): pure
+# tensors in, pure tensors out, a fake implementation for tracing / export.
+#   params: W12 [3*2R][Cin], B12, W3 [3*Cout][Cin], B3, W4 [3][Cout][R], B4, PA [3][V][V], alpha [1], sy, ty [Cout] (unit_gcn.bn
+#           folded), Wd [Cout][Cin], bd (down, folded; empty if none), Wo [Cout][Cout], bo (offset_conv folded), We [Cout][Cout], be
+#           (entry convs of the temporal + pooled branches, then the plain branch, folded), sp, tp [Cb] (pooled branch's
+#           BatchNorm), Wr [Cout][Cres], br (residual unit_tcn folded; empty if none), then Wt_b [Cb][Cb*ks], bt_b per branch
+#   geom:   R, unit_gcn residual (0 zero | 1 identity | 2 conv), Cb, nb, ks, stride, block residual (0 | 1 | 2), dilations
+# Returns (out (N, Cout, T2, V), xpart (N, ceil(T2/4), Cout, V)): xpart = per-tile frame sums of out, the next block's input.
+# ----------------------------------------------------------------------------------------------------------------------
+def _opt(t):
+    return None if t is None or t.numel() == 0 else t.data_ptr()
+
+
+@torch.library.custom_op('tamgcn::tcn_gcn_unit_eval', mutates_args=())
+def tcn_gcn_unit_eval(x: Tensor, xpart: Optional[Tensor], params: List[Tensor], geom: List[int]) -> Tuple[Tensor, Tensor]:
+    lib = _lib.load()
+    if not x.is_cuda or x.dtype != torch.float32:
+        raise RuntimeError('tamgcn::tcn_gcn_unit_eval: expected a float32 HIP (cuda) tensor; there is no CPU path')
+    x = x.contiguous()
+    (W12, B12, W3, B3, W4, B4, PA, alpha, sy, ty, Wd, bd, Wo, bo, We, be, sp, tp, Wr, br), rest = params[:20], params[20:]
+    R, gmode, Cb, nb, ks, stride, rmode = geom[:7]
+    dils = geom[7:7 + nb]
+    N, Cin, T, V = x.shape
+    Cout = W3.shape[0] // 3
+    dev = x.device
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    E = torch.empty(N, 3, Cout, V, V, device=dev)
+    ws = torch.empty(4, N, Cout, T, V, device=dev)               # y + res, res - y, g, h
+    sm, df, g, h = ws[0], ws[1], ws[2], ws[3]
+    d = _lib.F2GcnDesc(N=N, Cin=Cin, Cout=Cout, T=T, V=V, S=3, R=R, res_mode=gmode,
+                       x=x.data_ptr(), w12=W12.data_ptr(), b12=B12.data_ptr(), w4=W4.data_ptr(), b4=B4.data_ptr(),
+                       A=PA.data_ptr(), alpha=alpha.data_ptr(), w3=W3.data_ptr(), b3=B3.data_ptr(),
+                       sy=sy.data_ptr(), ty=ty.data_ptr(), wd=_opt(Wd), bd=_opt(bd),
+                       E=E.data_ptr(), sum=sm.data_ptr(), diff=df.data_ptr(), xpart=_opt(xpart))
+    _lib.check(lib.tamgcn_f2_e(C.byref(d), st), 'tamgcn_f2_e')
+    _lib.check(lib.tamgcn_f2_gcn(C.byref(d), st), 'tamgcn_f2_gcn')
+    q = _lib.F2GemmDesc(N=N, K=Cout, M=Cout, T=T, V=V, mode=0, relu_rows=0, x=df.data_ptr(), w=Wo.data_ptr(), b=bo.data_ptr(),
+                        add=sm.data_ptr(), out=g.data_ptr())
+    _lib.check(lib.tamgcn_f2_gemm(C.byref(q), st), 'tamgcn_f2_gemm')
+    q = _lib.F2GemmDesc(N=N, K=Cout, M=Cout, T=T, V=V, mode=1, relu_rows=(nb + 1) * Cb, x=g.data_ptr(), w=We.data_ptr(),
+                        b=be.data_ptr(), add=None, out=h.data_ptr())
+    _lib.check(lib.tamgcn_f2_gemm(C.byref(q), st), 'tamgcn_f2_gemm')
+    T2 = (T - 1) // stride + 1
+    out = torch.empty(N, Cout, T2, V, device=dev)
+    xp = torch.empty(N, (T2 + 3) // 4, Cout, V, device=dev)      # per-tile frame sums: the next block's xbar
+    t = _lib.F2TcnDesc(N=N, Cin=Wr.shape[1] if rmode == 2 else Cin, Cout=Cout, T=T, V=V, stride=stride, Cb=Cb, nb=nb, ks=ks,
+                       res_mode=rmode, h=h.data_ptr(), sp=sp.data_ptr(), tp=tp.data_ptr(), x=x.data_ptr(), wr=_opt(Wr), br=_opt(br),
+                       out=out.data_ptr(), xpart=xp.data_ptr())
+    for i in range(nb):
+        t.dil[i] = dils[i]
+        t.wt[i] = rest[2 * i].data_ptr()
+        t.bt[i] = rest[2 * i + 1].data_ptr()
+    _lib.check(lib.tamgcn_f2_tcn(C.byref(t), st), 'tamgcn_f2_tcn')
+    return out, xp
+
+
+@tcn_gcn_unit_eval.register_fake
+def _(x, xpart, params, geom):
+    N, _, T, V = x.shape
+    Cout = params[2].shape[0] // 3
+    T2 = (T - 1) // geom[5] + 1
+    return x.new_empty(N, Cout, T2, V), x.new_empty(N, (T2 + 3) // 4, Cout, V)

@@ -13,7 +13,10 @@ backward is itself a registered op:
     tamgcn::stream_derive(x, parent, mode) -> stream            feeder/feeder_nucla_gcn.py:119-127
     tamgcn::feeder_transform(raw, offsets, rot, idx, parent, V, time_steps, center_joint, mode) -> clips   :85-130
 
-The block-level nodes (unit_gcn / MultiScale_TemporalConv / TCN_GCN_unit / st_gcn) stay ``autograd.Function``s: they update
+    tamgcn::tcn_gcn_unit_eval(x, xpart, params, geom) -> (out, xpart)   the whole eval-mode TCN_GCN_unit (:266-284) for small
+                                                 batches, BatchNorm folded; registered by tam_gcn_amd/f2.py with the engine that uses it
+
+The TRAINING block-level nodes (unit_gcn / MultiScale_TemporalConv / TCN_GCN_unit / st_gcn) stay ``autograd.Function``s: they update
 BatchNorm running statistics in place, keep ~20 intermediate tensors between forward and backward and take their
 configuration from the nn.Module; the modules ``CTRGC``, ``CrossEntropyLoss``, the ST-GCN per-position classifier and the
 model heads call the registered ops."""

@@ -53,10 +53,8 @@ def test_every_block_against_the_fp64_oracle(shape, golden_models):
     m = m.to(DEV).eval()
     eng = f2.FusedEval(m)
     blocks = eng._packed(torch.device(DEV))
-    import ctypes as C
-    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     for i, (b, xin, ref) in enumerate(zip(blocks, ins, outs), 1):
-        got = eng._block(b, xin.float().to(DEV).contiguous(), st).double().cpu()
+        got = eng._block(b, xin.float().to(DEV).contiguous()).double().cpu()
         assert got.shape == ref.shape, (i, got.shape, ref.shape)
         err = float((got - ref).abs().max() / ref.abs().max())
         assert err <= 2e-5, f'l{i}: {err:.3e} of max|ref|'
@@ -174,17 +172,37 @@ def test_graph_replay_and_launch_count():
             return w
     real = _lib.load()
     cnt = Count(real)
-    eng = m.__dict__['_tamgcn_f2']
-    eng.lib = cnt
     _lib._lib = cnt
     try:
         with torch.no_grad():
             m(make_input((1, 3, 52, 20, 1), seed=9).to(DEV))
     finally:
         _lib._lib = real
-        eng.lib = real
     assert cnt.n <= 56, (cnt.n, cnt.names)
     assert sum(n.startswith('tamgcn_f2_') for n in cnt.names) == 50
+
+
+def test_block_is_a_registered_operator():
+    """torch.ops.tamgcn.tcn_gcn_unit_eval: schema and fake-tensor checks (torch.library.opcheck), traced by torch.compile
+    without a graph break."""
+    m, _ = _model()
+    m = m.to(DEV).eval()
+    eng = f2.FusedEval(m)
+    blocks = eng._packed(torch.device(DEV))
+    x = make_input((2, 64, 12, 20), seed=3).to(DEV)
+    for b in (blocks[1], blocks[4]):                        # identity residual; 64 -> 128, stride 2, convolutional residuals
+        torch.library.opcheck(torch.ops.tamgcn.tcn_gcn_unit_eval.default, (x, None, b.params, b.geom),
+                              test_utils=('test_schema', 'test_faketensor'))
+    b = blocks[4]
+
+    def f(x):
+        out, xp = torch.ops.tamgcn.tcn_gcn_unit_eval(x, None, b.params, b.geom)
+        return out * 2, xp
+    with torch.no_grad():
+        ref = f(x)
+        got = torch.compile(f, fullgraph=True, backend='eager')(x)
+    assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1]) and tuple(ref[0].shape) == (2, 128, 6, 20)
+    assert float((ref[1].sum(1) - ref[0].sum(2) / 2).abs().max()) <= 1e-5 * float(ref[0].abs().max()) * 6     # xpart = frame sums of out
 
 
 def test_engine_argument_guards():
