@@ -591,7 +591,8 @@ typedef __attribute__((address_space(3))) void* tg_lptr;
 __device__ __forceinline__ void wait_vmcnt(int n) {     // n is wave-uniform
     switch (n) {
         TG_VMCNT_CASE(0) TG_VMCNT_CASE(1) TG_VMCNT_CASE(2) TG_VMCNT_CASE(3) TG_VMCNT_CASE(4)
-        TG_VMCNT_CASE(5) TG_VMCNT_CASE(6) TG_VMCNT_CASE(7) TG_VMCNT_CASE(8)
+        TG_VMCNT_CASE(5) TG_VMCNT_CASE(6) TG_VMCNT_CASE(7) TG_VMCNT_CASE(8) TG_VMCNT_CASE(9) TG_VMCNT_CASE(10)
+        TG_VMCNT_CASE(11) TG_VMCNT_CASE(12) TG_VMCNT_CASE(13) TG_VMCNT_CASE(14) TG_VMCNT_CASE(15)
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 }
@@ -723,23 +724,36 @@ __global__ __launch_bounds__(G_NT, 2) void conv1x1_glds_kernel(const ConvArgs a,
 
     TG_T(tt0);
     const int nch = K / BK;
-    issue(0);                                                     // the first two chunks travel while the prologue coefficients are
-    if (nch > 1) issue(1);                                        // fetched (they used to wait for that round trip: 0-7 % per launch, K = 256)
-    for (int e = tid; e < K; e += G_NT) {
-        int ch = a.src.coff + e;
-        cf[e] = a.src.coef ? a.src.coef[ch] : 1.f;
-        cf[K + e] = (a.src.coef && a.src.x2) ? a.src.coef[a.src.ctot + ch] : 0.f;
-        cf[2 * K + e] = a.src.coef ? a.src.coef[2 * a.src.ctot + ch] : 0.f;
+    // The prologue coefficients are requested FIRST and the whole ring (three chunks) right behind them: vmcnt retires in
+    // order, so waiting for "all but the chunks" is waiting for the coefficients only, and a raw barrier publishes them
+    // (__syncthreads would drain the chunks too -- the kernel used to start its K loop with an empty third stage).
+    float cfr[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                                 // K <= 1024 (host-checked)
+        const int e = tid + i * G_NT, ch = a.src.coff + (e < K ? e : 0);
+        cfr[i][0] = a.src.coef ? a.src.coef[ch] : 1.f;
+        cfr[i][1] = (a.src.coef && a.src.x2) ? a.src.coef[a.src.ctot + ch] : 0.f;
+        cfr[i][2] = a.src.coef ? a.src.coef[2 * a.src.ctot + ch] : 0.f;
     }
-    __syncthreads();                                              // cf visible (this barrier also waits for the two chunks)
+    const int npre = nch < G_NST ? nch : G_NST;
+    issue(0);
+    if (nch > 1) issue(1);
+    if (nch > 2) issue(2);
+    wait_vmcnt(npre * nissue);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = tid + i * G_NT;
+        if (e < K) { cf[e] = cfr[i][0]; cf[K + e] = cfr[i][1]; cf[2 * K + e] = cfr[i][2]; }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     TG_T(tt1); TG_ACC(0, tt1 - tt0);
     for (int c = 0; c < nch; ++c) {
         TG_T(ta);
-        wait_vmcnt(c + 1 < nch ? nissue : 0);                     // this wave's pieces of chunk c have landed
+        wait_vmcnt(c == 0 ? (npre - 1) * nissue : (c + 1 < nch ? nissue : 0));   // this wave's pieces of chunk c have landed
         TG_T(tb); TG_ACC(2, tb - ta);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // everyone's have; chunk c-1 fully consumed
         TG_T(tc); TG_ACC(4, tc - tb);
-        if (c + 2 < nch) issue(c + 2);
+        if (c > 0 && c + 2 < nch) issue(c + 2);
         TG_T(td); TG_ACC(5, td - tc);
         const float* st = smem + (c % G_NST) * STG;
         const float* As = st + BK * G_PBMAX * NSRC;

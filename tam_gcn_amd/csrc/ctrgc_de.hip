@@ -12,6 +12,8 @@
 // per-channel-tile tail that was latency-bound with a single 159 KB workgroup per CU.
 #include "common.h"
 
+TG_TRACE_DEFINE(tamgcn_trace_read_de)
+
 namespace {
 
 // ---------------------------------------------------------------------------------------------
@@ -198,8 +200,281 @@ constexpr int tail_pitch(int vv) {   // smallest pitch >= vv with pitch % 16 == 
     return p;
 }
 
-template <int V, int RT>
+typedef __attribute__((address_space(1))) const void* de_gptr;
+typedef __attribute__((address_space(3))) void* de_lptr;
+
+template <int V, int RT, bool DBR>
 __global__ __launch_bounds__(512) void ctrgc_de_tail_kernel(const TailArgs a) {
+    // 512 threads: the kernel holds one workgroup per CU at R = 32 (D alone is 51 KB), so parallelism inside the
+    // workgroup is what hides its latencies (256 threads = one wave per SIMD measured 400 us at C = 256).
+    // Round 3: the dE chunk (16 channels x V*V floats = 25 whole 1 KB pieces when V = 20) reaches LDS by LDS-DMA into one of two
+    // buffers while the previous chunk is worked on -- no register staging, no commit pass with its index arithmetic -- and
+    // the per-wave partial dW4 tiles are double-buffered too (DBR), so a chunk costs ONE barrier instead of three; at R <= 8 the
+    // kernel keeps one partial buffer and 73 KB instead, so that two workgroups share a CU.
+    constexpr int VV = V * V, PD = tail_pitch(VV), NT = 512, NW = 8;
+    constexpr int PE = VV;                       // dE chunk rows are contiguous (the DMA image of a contiguous run); 400 = 16 (mod 64):
+    //                                              the four k rows of a dG fragment read sit 16 banks apart; the dW4 reads (13 per wave and
+    //                                              chunk) take a 4-way conflict
+    constexpr int CH = 16 * PE, CHP = (CH + 255) & ~255;           // chunk floats, padded to whole pieces (V = 25: 40 pieces, the last partial)
+    constexpr int NPIECE = CHP / 256, PPW = (NPIECE + NW - 1) / NW;
+    constexpr int NCT = (VV + 15) / 16, TPW = (NCT + NW - 1) / NW;
+    constexpr int NA = (VV + NT - 1) / NT;
+    constexpr int KST = (VV + 3) / 4;
+    constexpr int NRED = DBR ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float red_alpha[NW];
+    float* DEs = smem;                           // [2][CHP]         dE chunks
+    float* red = DEs + 2 * CHP;                  // [NRED][NW][16][RT*16]
+    float* Ds = red + NRED * NW * 16 * RT * 16;  // [R][PD]          D, later dS in place
+    float* PQ = Ds + a.R * PD;                   // [p | q][R][V]
+    const int grp = blockIdx.x % a.G, ns = blockIdx.x / a.G;
+    const int n = ns / a.S, s = ns - n * a.S;
+    const int cg = a.Cout / a.G, cbeg = grp * cg, cend = cbeg + cg;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, mj = lane & 15, mkq = lane >> 4;
+    const long long NV = (long long)a.N * V;
+    const float alpha = a.alpha[0];
+
+    const float* dEg = a.dE + (((long long)n * a.S + s) * a.Cout) * VV;
+    auto issue = [&](int c0, int buf) {          // wave-uniform pieces; lanes past the chunk re-read its last slot into the padding
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int piece = wave * PPW + i;
+            if (piece < NPIECE) {
+                int f = piece * 256 + lane * 4;
+                if (f > CH - 4) f = CH - 4;
+                __builtin_amdgcn_global_load_lds((de_gptr)(dEg + (long long)c0 * VV + f), (de_lptr)(DEs + buf * CHP + piece * 256), 16, 0, 0);
+            }
+        }
+    };
+    TG_T(tt0);
+    issue(cbeg, 0);
+    {   // p, q of this (n, subset) -> LDS in one batch of loads, then D[r][uv] = tanh(p[r][u] - q[r][v]) from LDS
+        const int cnt = 2 * a.R * V;
+        constexpr int MAXL = 8;
+        for (int e0 = tid; e0 < cnt; e0 += MAXL * NT) {
+            float t[MAXL];
+#pragma unroll
+            for (int i = 0; i < MAXL; ++i) {
+                const int e = e0 + i * NT;
+                const int row = (e < cnt ? e : 0) / V, v = (e < cnt ? e : 0) - row * V;
+                t[i] = a.pq[((long long)s * 2 * a.R + row) * NV + (long long)n * V + v];
+            }
+#pragma unroll
+            for (int i = 0; i < MAXL; ++i) {
+                const int e = e0 + i * NT;
+                if (e < cnt) PQ[e] = t[i];
+            }
+        }
+        __syncthreads();
+        const int total = a.R * VV;
+        for (int e = tid; e < total; e += NT) {
+            const int r = e / VV, uv = e - r * VV;
+            const int u = uv / V, v = uv - u * V;
+            Ds[r * PD + uv] = fast_tanh(PQ[r * V + u] - PQ[(a.R + r) * V + v]);
+        }
+    }
+    f32x4 accG[TPW][RT];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) accG[j][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float accA[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) accA[i] = 0.f;
+    float dalpha_acc = 0.f;
+
+    // Small operands of a chunk -- the W4^T fragment A[i = r][k = c], and the scalars dalpha needs (b4[c] for the db4 pass, w4[c][r]
+    // for the flushed dW4 entry).  vmcnt retires IN ORDER: a load consumed inside the loop body waits for the whole DMA chunk
+    // issued in front of it, and hipcc is free to sink a plain load below the DMA -- both serialised the prefetch (tools/
+    // de_tail_phases.py: 70 % of a chunk's time were such waits).  They are therefore inline-asm loads, issued one chunk ahead
+    // and IN FRONT of that iteration's DMA, and first touched right after the next top-of-loop `s_waitcnt vmcnt(0)`.
+    constexpr int NFL = (16 * RT * 16 + NT - 1) / NT;               // flush items per thread (1)
+    const int dbc = (tid >> 4) & 15;                                // this thread's channel in the db4 pass
+    float aw[RT][4], awn[RT][4], w4c[NFL], w4p[NFL], w4n[NFL], b4c = 0.f, b4n;
+    auto gload = [](float& dst, const float* ptr) { asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory"); };
+    auto fetch_next = [&](int c0) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const int r = rt * 16 + mj < a.R ? rt * 16 + mj : 0;
+                gload(awn[rt][k4], a.w4 + ((long long)s * a.Cout + c0 + k4 * 4 + mkq) * a.R + r);
+            }
+#pragma unroll
+        for (int i = 0; i < NFL; ++i) {
+            const int e = tid + i * NT, c = (e / (RT * 16)) & 15, r = e - (e / (RT * 16)) * (RT * 16);
+            gload(w4n[i], a.w4 + ((long long)s * a.Cout + c0 + c) * a.R + (r < a.R ? r : 0));
+        }
+        gload(b4n, a.b4 + s * a.Cout + c0 + dbc);
+    };
+    fetch_next(cbeg);
+#pragma unroll
+    for (int i = 0; i < NFL; ++i) { w4p[i] = 0.f; w4c[i] = 0.f; }
+    // the partial dW4 tiles of one chunk -> global (fixed order over the waves)
+    auto flush_red = [&](int c0, const float* rb, const float (&w)[NFL]) {
+#pragma unroll
+        for (int i = 0; i < NFL; ++i) {
+            const int e = tid + i * NT;
+            const int c = e / (RT * 16), r = e - c * (RT * 16);
+            if (e < 16 * RT * 16 && r < a.R) {
+                float t = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < NW; ++wv) t += rb[(wv * 16 + c) * (RT * 16) + r];
+                const long long wi = ((long long)s * a.Cout + c0 + c) * a.R + r;
+                a.dw4_part[(long long)n * a.S * a.Cout * a.R + wi] = alpha * t;
+                dalpha_acc = fmaf(w[i], t, dalpha_acc);
+            }
+        }
+    };
+
+    int ci = 0;
+    TG_T(tt1); TG_ACC(0, tt1 - tt0);
+    for (int c0 = cbeg; c0 < cend; c0 += 16, ++ci) {
+        const float* DE = DEs + (ci & 1) * CHP;
+        float* rb = red + (NRED == 2 ? (ci & 1) : 0) * NW * 16 * RT * 16;
+        TG_T(ta);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of chunk c0 and its small operands have landed
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) aw[rt][k4] = rt * 16 + mj < a.R ? awn[rt][k4] : 0.f;
+#pragma unroll
+        for (int i = 0; i < NFL; ++i) { w4p[i] = w4c[i]; w4c[i] = w4n[i]; }
+        b4c = b4n;
+        TG_T(tb); TG_ACC(1, tb - ta);
+        __syncthreads();                                           // everyone's have; chunk c0 - 16 is consumed (and D is filled)
+        TG_T(tc); TG_ACC(2, tc - tb);
+        if (c0 + 16 < cend) { fetch_next(c0 + 16); issue(c0 + 16, (ci + 1) & 1); }
+        if (NRED == 2 && ci > 0) flush_red(c0 - 16, red + ((ci - 1) & 1) * NW * 16 * RT * 16, w4p);
+        TG_T(td); TG_ACC(3, td - tc);
+        // dG[r][uv] += sum_c W4[c][r] dE[c][uv]
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+            const int ct = wave + j * NW;
+            if (ct < NCT) {
+                const int col = ct * 16 + mj;
+                const int colc = col < VV ? col : VV - 1;
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    float bv = DE[(k4 * 4 + mkq) * PE + colc];
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) accG[j][rt] = mfma16(aw[rt][k4], bv, accG[j][rt]);
+                }
+            }
+        }
+        TG_T(te); TG_ACC(4, te - td);
+        // dA partial: sum over channels
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            int uv = tid + i * NT;
+            if (uv < VV) {
+                float t = 0.f;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) t += DE[c * PE + uv];
+                accA[i] += t;
+            }
+        }
+        TG_T(tf); TG_ACC(5, tf - te);
+        // db4raw[c] = sum_uv dE[c][uv]
+        {
+            const int c = (tid >> 4) & 15, l16 = tid & 15;          // threads 256.. shadow 0..255 (no second write)
+            float t = 0.f;
+            for (int uv = l16; uv < VV; uv += 16) t += DE[c * PE + uv];
+            t = wave_sum16(t);
+            if (l16 == 0 && tid < 256) {
+                a.db4_part[((long long)n * a.S + s) * a.Cout + c0 + c] = alpha * t;
+                dalpha_acc = fmaf(b4c, t, dalpha_acc);
+            }
+        }
+        TG_T(tg); TG_ACC(6, tg - tf);
+        // dW4raw[c][r] = sum_uv dE[c][uv] D[r][uv]: K = VV split over the waves
+        {
+            f32x4 accW[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) accW[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int st = wave; st < KST; st += NW) {
+                const int k = st * 4 + mkq;
+                const bool kok = k < VV;
+                float av = kok ? DE[mj * PE + k] : 0.f;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const int r = rt * 16 + mj;
+                    float bv = (kok && r < a.R) ? Ds[r * PD + k] : 0.f;
+                    accW[rt] = mfma16(av, bv, accW[rt]);
+                }
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) rb[(wave * 16 + mkq * 4 + rr) * (RT * 16) + rt * 16 + mj] = accW[rt][rr];
+        }
+        TG_T(th); TG_ACC(7, th - tg);
+        if (NRED == 1) {
+            __syncthreads();
+            flush_red(c0, rb, w4c);
+        }
+        TG_T(ti); TG_ACC(10, ti - th);
+    }
+    if (NRED == 2) {
+        __syncthreads();
+        flush_red(cend - 16, red + ((ci - 1) & 1) * NW * 16 * RT * 16, w4c);   // (no rotation after the last chunk)
+    }
+    TG_T(tz0);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        int uv = tid + i * NT;
+        if (uv < VV) a.dA_part[(((long long)n * a.G + grp) * a.S + s) * VV + uv] = accA[i];
+    }
+    __syncthreads();                         // every wave is done reading D
+    // dS[r][uv] = alpha * dG * (1 - D^2), in place over D
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int ct = wave + j * NW;
+        const int col = ct * 16 + mj;
+        if (ct < NCT && col < VV) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int r = rt * 16 + mkq * 4 + rr;
+                    if (r < a.R) {
+                        float d = Ds[r * PD + col];
+                        Ds[r * PD + col] = alpha * accG[j][rt][rr] * (1.f - d * d);
+                    }
+                }
+        }
+    }
+    __syncthreads();
+    // dp[r][u] = sum_v dS[r][u][v];  dq[r][v] = -sum_u dS[r][u][v]
+    for (int e = tid; e < a.R * V * 2; e += NT) {
+        const int which = e / (a.R * V);
+        const int rem = e - which * a.R * V;
+        const int r = rem / V, k = rem - r * V;
+        float t = 0.f;
+        if (which == 0) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) t += Ds[r * PD + k * V + v];
+        } else {
+#pragma unroll
+            for (int u = 0; u < V; ++u) t -= Ds[r * PD + u * V + k];
+        }
+        a.dpq[(((long long)grp * a.S * 2 + s * 2 + which) * a.R + r) * NV + (long long)n * V + k] = t;
+    }
+    dalpha_acc = wave_sum64(dalpha_acc);
+    if (lane == 0) red_alpha[wave] = dalpha_acc;
+    __syncthreads();
+    if (tid == 0) {
+        float t = 0.f;
+        for (int w = 0; w < NW; ++w) t += red_alpha[w];
+        a.dalpha_part[(n * a.S + s) * a.G + grp] = t;
+    }
+    TG_T(tz1); TG_ACC(11, tz1 - tz0); TG_ACC(8, tz1 - tt0); TG_ACC(9, 1);
+}
+
+// The register-staged form of the tail (one dE buffer, the next chunk prefetched into registers): V = 25, where two DMA buffers
+// (2 x 41 KB) do not fit beside D (80 KB at R = 32).
+template <int V, int RT>
+__global__ __launch_bounds__(512) void ctrgc_de_tail_reg_kernel(const TailArgs a) {
     // 512 threads: the kernel holds one workgroup per CU at R = 32 (D alone is 51 KB), so parallelism inside the
     // workgroup is what hides its latencies (256 threads = one wave per SIMD measured 400 us at C = 256)
     constexpr int VV = V * V, PD = tail_pitch(VV), NT = 512, NW = 8;
@@ -417,7 +692,13 @@ void allow_lds(K kernel, size_t lds, tg_devmask* done) {       // once per insta
 }
 
 template <int V>
-size_t tail_lds(int R, int RT) { return sizeof(float) * ((size_t)(R + 16) * tail_pitch(V * V) + 8 * 16 * RT * 16 + 2 * (size_t)R * V); }
+size_t tail_lds(int R, int RT, bool dbr) {
+    const size_t chp = ((size_t)16 * V * V + 255) & ~(size_t)255;
+    return sizeof(float) * (2 * chp + (size_t)(dbr ? 2 : 1) * 8 * 16 * RT * 16 + (size_t)R * tail_pitch(V * V) + 2 * (size_t)R * V);
+}
+
+template <int V>
+size_t tail_reg_lds(int R, int RT) { return sizeof(float) * ((size_t)(R + 16) * tail_pitch(V * V) + 8 * 16 * RT * 16 + 2 * (size_t)R * V); }
 
 }  // namespace
 
@@ -443,13 +724,22 @@ extern "C" int tamgcn_ctrgc_bwd_de_acc(const tamgcn_ctrgc_desc* d, const tamgcn_
     return 0;
 }
 
-#define DE_TAIL_CASE(VV_, RT_)                                                                                         \
+#define DE_TAIL_REG_CASE(VV_, RT_)                                                                                     \
     if (d->V == VV_ && rt == RT_) {                                                                                    \
         static tg_devmask flag = 0;                                                                                    \
-        const size_t lds = tail_lds<VV_>(d->R, RT_);                                                                   \
-        allow_lds(ctrgc_de_tail_kernel<VV_, RT_>, tail_lds<VV_>(32, 2), &flag);                                        \
-        hipLaunchKernelGGL((ctrgc_de_tail_kernel<VV_, RT_>), dim3(d->N * d->S * groups), dim3(512), lds, (hipStream_t)stream, a); \
-        tamgcn_note_kernel("ctrgc_de_tail_kernel<%d, %d>", VV_, RT_);                                                  \
+        const size_t lds = tail_reg_lds<VV_>(d->R, RT_);                                                               \
+        allow_lds(ctrgc_de_tail_reg_kernel<VV_, RT_>, tail_reg_lds<VV_>(32, 2), &flag);                                \
+        hipLaunchKernelGGL((ctrgc_de_tail_reg_kernel<VV_, RT_>), dim3(d->N * d->S * groups), dim3(512), lds, (hipStream_t)stream, a); \
+        tamgcn_note_kernel("ctrgc_de_tail_reg_kernel<%d, %d>", VV_, RT_);                                              \
+        launched = true;                                                                                               \
+    }
+#define DE_TAIL_CASE(VV_, RT_, DBR_)                                                                                   \
+    if (d->V == VV_ && rt == RT_ && dbr == DBR_) {                                                                     \
+        static tg_devmask flag = 0;                                                                                    \
+        const size_t lds = tail_lds<VV_>(d->R, RT_, DBR_);                                                             \
+        allow_lds(ctrgc_de_tail_kernel<VV_, RT_, DBR_>, tail_lds<VV_>(RT_ == 2 ? 32 : 16, RT_, DBR_), &flag);          \
+        hipLaunchKernelGGL((ctrgc_de_tail_kernel<VV_, RT_, DBR_>), dim3(d->N * d->S * groups), dim3(512), lds, (hipStream_t)stream, a); \
+        tamgcn_note_kernel("ctrgc_de_tail_kernel<%d, %d, %d>", VV_, RT_, (int)DBR_);                                   \
         launched = true;                                                                                               \
     }
 
@@ -466,7 +756,13 @@ extern "C" int tamgcn_ctrgc_bwd_de_tail(const tamgcn_ctrgc_desc* d, const float*
     a.dA_part = dA_part; a.dw4_part = dw4_part; a.db4_part = db4_part; a.dalpha_part = dalpha_part; a.dpq = dpq;
     const int rt = d->R <= 16 ? 1 : 2;
     bool launched = false;
-    DE_TAIL_CASE(20, 1) else DE_TAIL_CASE(20, 2) else DE_TAIL_CASE(25, 1) else DE_TAIL_CASE(25, 2)
+    // V = 20: the LDS-DMA form at R <= 8 (73 KB, one partial buffer: two workgroups per CU) and at R > 16 (140 KB, everything
+    // double-buffered, one per CU either way); 8 < R <= 16 stays on the register-staged form, whose 62 KB put two workgroups
+    // on a CU where the DMA form's 95 KB put one (measured: 238 vs 254 us per dE chain at 128 channels)
+    const bool dbr = d->R > 16, reg16 = d->V == 20 && d->R > 8 && d->R <= 16;
+    if (reg16) { DE_TAIL_REG_CASE(20, 1) }
+    else DE_TAIL_CASE(20, 1, false) else DE_TAIL_CASE(20, 2, true)
+    else DE_TAIL_REG_CASE(25, 1) else DE_TAIL_REG_CASE(25, 2)
     TG_CHECK(launched, "tamgcn_ctrgc_bwd_de_tail: unsupported V=%d (V in {20,25})", d->V);
     TG_LAUNCH_CHECK("tamgcn_ctrgc_bwd_de_tail");
     return 0;
