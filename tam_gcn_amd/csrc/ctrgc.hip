@@ -134,8 +134,7 @@ template <int V>
 __global__ __launch_bounds__(512) void ctrgc_E_kernel(const EArgs a) {
     constexpr int VV = V * V, NT = 512, NW = 8, NTILE = (VV + 15) / 16, NIT = (NTILE + NW - 1) / NW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Tt = smem;                         // [16][VV] finished tile
-    float* Ds = Tt + 16 * VV;                 // [R][VV]
+    float* Ds = smem;                         // [R][VV]
     float* PQ = Ds + a.R * VV;                // [p|q][R][V]
     const int n = blockIdx.x / a.S, s = blockIdx.x - n * a.S;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kq = lane >> 4;
@@ -182,7 +181,18 @@ __global__ __launch_bounds__(512) void ctrgc_E_kernel(const EArgs a) {
     fetch(0);
     __syncthreads();
     float* Eg = a.E + ((long long)n * a.S + s) * a.Cout * VV;
+    // Tiles leave straight from the accumulators: a lane holds four channels of one (u, v) column, so a store instruction
+    // writes four 64-byte row segments (round 3: the staging tile with its two barriers per 16 channels kept the waves in
+    // step for a kernel that only has to stream 173 MB out)
+    float awn[8], b4n[4];
     for (int c0 = 0; c0 < a.Cout; c0 += 16) {
+        if (c0 + 16 < a.Cout) {                        // next tile's fragment in flight under this tile's MFMAs and stores
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                awn[k] = (k * 4 + kq < a.R) ? a.w4[((long long)s * a.Cout + c0 + 16 + j) * a.R + k * 4 + kq] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b4n[r] = a.b4[s * a.Cout + c0 + 16 + kq * 4 + r];
+        }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int ct = wave + it * NW;
@@ -195,15 +205,16 @@ __global__ __launch_bounds__(512) void ctrgc_E_kernel(const EArgs a) {
                     if (k * 4 < a.R) acc = mfma16(aw[k], Ds[(k * 4 + kq) * VV + colc], acc);
                 if (col < VV) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) Tt[(kq * 4 + r) * VV + col] = alpha * (acc[r] + b4r[r]) + Ar[it];
+                    for (int r = 0; r < 4; ++r) Eg[(long long)(c0 + kq * 4 + r) * VV + col] = alpha * (acc[r] + b4r[r]) + Ar[it];
                 }
             }
         }
-        if (c0 + 16 < a.Cout) fetch(c0 + 16);           // in flight under the store pass
-        __syncthreads();
-        for (int e = tid; e < 16 * VV / 4; e += NT)
-            reinterpret_cast<float4*>(Eg + (long long)c0 * VV)[e] = reinterpret_cast<const float4*>(Tt)[e];
-        __syncthreads();
+        if (c0 + 16 < a.Cout) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) aw[k] = awn[k];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b4r[r] = b4n[r];
+        }
     }
 }
 
@@ -730,7 +741,7 @@ extern "C" int tamgcn_ctrgc_build_e(const tamgcn_ctrgc_desc* d, float* E, void* 
     EArgs a;
     a.N = d->N; a.Cout = d->Cout; a.S = d->S; a.R = d->R;
     a.pq = d->pq; a.w4 = d->w4; a.b4 = d->b4; a.A = d->A; a.alpha = d->alpha; a.E = E;
-    const size_t lds = sizeof(float) * ((size_t)(16 + d->R) * d->V * d->V + 2 * (size_t)d->R * d->V);
+    const size_t lds = sizeof(float) * ((size_t)d->R * d->V * d->V + 2 * (size_t)d->R * d->V);
     if (d->V == 20) {
         static tg_devmask f = 0;
         tg_allow_lds((const void*)ctrgc_E_kernel<20>, 160 * 1024, &f);
