@@ -327,11 +327,10 @@ def main():
     ap.add_argument('--batch', type=int, default=None, help='clips per GPU (per stream); default 256, 128 for --config 4stream')
     ap.add_argument('--config', choices=('ucla', '4stream'), default='ucla')
     ap.add_argument('--no-graph', action='store_true')
-    ap.add_argument('--fork-streams', type=int, default=0,
-                    help='4stream: number of HIP streams the four models are spread over (forward and, through autograd, backward): '
-                         '0 or 1 = one after the other on the current stream (default); 2 or 4 = that many at a time, with --no-graph '
-                         'only: eagerly the step is bit-identical to the one-stream step, replayed from a HIP graph one model\'s '
-                         'gradients come back 1e-4 off (profiles/r03_stream_capture_bisect.txt)')
+    ap.add_argument('--fork-streams', type=int, default=None,
+                    help='4stream: number of HIP streams the four models are spread over (forward and, through autograd, backward), '
+                         'inside the HIP graph or eagerly: 4 (default) or 2 = that many at a time, 0 or 1 = one after the other on the '
+                         'current stream.  Bit-identical to the one-stream step either way (tests/test_gpu_configs.py)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -339,6 +338,7 @@ def main():
     # barriers, max-over-ranks clock, rank 0's JSON line) on CPU tensors over gloo with a stand-in gradient fill instead
     # of the HIP model: what tests/test_distributed_cpu.py drives with world size 2.  Never a measurement: `value` is null.
     rehearsal = os.environ.get('TAMGCN_BENCH_REHEARSAL') == '1'
+    nfork = 0
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         _self_launch(args.gpus, sys.argv[1:])
     rank = int(os.environ.get('RANK', 0))
@@ -403,11 +403,9 @@ def main():
         from tam_gcn_amd.functional import CrossEntropyLoss
         ce = CrossEntropyLoss()                             # the harness's nn.CrossEntropyLoss() as two HIP launches (row f1)
 
+        if args.fork_streams is None:
+            args.fork_streams = 4 if four and not rehearsal else 0
         nfork = args.fork_streams if four and args.fork_streams > 1 else 0
-        if nfork > 1 and not args.no_graph:
-            raise RuntimeError('bench.py: --fork-streams > 1 needs --no-graph: a HIP graph that holds several model branches side by '
-                               'side replays with one model\'s gradients ~1e-4 off on this stack, while the same streams are '
-                               'bit-identical eagerly (profiles/r03_stream_capture_bisect.txt)')
         fork = nfork > 1
         pool = [torch.cuda.Stream(dev) for _ in range(nfork)]
         model_streams = [pool[i % nfork] for i in range(len(streams))] if fork else []     # models i, i + nfork, ... share a stream
@@ -570,7 +568,7 @@ def main():
                                     f'N-UCLA joint stream, {B} clips/GPU x (3,64,20,1), models.ctrgcn.Model') +
                                    ' fwd+CE+bwd+grad-allreduce+SGD step, train-mode BN',
                        'global_batch': world * B, 'streams': len(streams), 'parallelism': f'dp{world}', 'launch': mode,
-                       'final_loss': final_loss, 'rehearsal': rehearsal},
+                       'model_streams': nfork, 'final_loss': final_loss, 'rehearsal': rehearsal},
             'roofline': roof, 'cpu_baseline': cpu, 'cpu_baseline_absent_because': cpu_why, 'ctrgc_fwd_layers': layer_rows,
             'abi_ms_per_2_steps': shares,
         }

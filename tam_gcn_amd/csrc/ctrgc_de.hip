@@ -227,6 +227,8 @@ __global__ __launch_bounds__(512) void ctrgc_de_tail_kernel(const TailArgs a) {
     float* red = DEs + 2 * CHP;                  // [NRED][NW][16][RT*16]
     float* Ds = red + NRED * NW * 16 * RT * 16;  // [R][PD]          D, later dS in place
     float* PQ = Ds + a.R * PD;                   // [p | q][R][V]
+    const int WQ = (16 * a.R + 255) & ~255;      // a chunk's W4 rows (16 channels x R, contiguous in global memory), whole pieces
+    float* W4s = PQ + ((2 * a.R * V + 3) & ~3);  // [2][WQ + 256]: W4 rows, then one piece slot whose first 16 floats are b4
     const int grp = blockIdx.x % a.G, ns = blockIdx.x / a.G;
     const int n = ns / a.S, s = ns - n * a.S;
     const int cg = a.Cout / a.G, cbeg = grp * cg, cend = cbeg + cg;
@@ -283,47 +285,43 @@ __global__ __launch_bounds__(512) void ctrgc_de_tail_kernel(const TailArgs a) {
     for (int i = 0; i < NA; ++i) accA[i] = 0.f;
     float dalpha_acc = 0.f;
 
-    // Small operands of a chunk -- the W4^T fragment A[i = r][k = c], and the scalars dalpha needs (b4[c] for the db4 pass, w4[c][r]
-    // for the flushed dW4 entry).  vmcnt retires IN ORDER: a load consumed inside the loop body waits for the whole DMA chunk
-    // issued in front of it, and hipcc is free to sink a plain load below the DMA -- both serialised the prefetch (tools/
-    // de_tail_phases.py: 70 % of a chunk's time were such waits).  They are therefore inline-asm loads, issued one chunk ahead
-    // and IN FRONT of that iteration's DMA, and first touched right after the next top-of-loop `s_waitcnt vmcnt(0)`.
-    constexpr int NFL = (16 * RT * 16 + NT - 1) / NT;               // flush items per thread (1)
-    const int dbc = (tid >> 4) & 15;                                // this thread's channel in the db4 pass
-    float aw[RT][4], awn[RT][4], w4c[NFL], w4p[NFL], w4n[NFL], b4c = 0.f, b4n;
-    auto gload = [](float& dst, const float* ptr) { asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory"); };
-    auto fetch_next = [&](int c0) {
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4) {
-                const int r = rt * 16 + mj < a.R ? rt * 16 + mj : 0;
-                gload(awn[rt][k4], a.w4 + ((long long)s * a.Cout + c0 + k4 * 4 + mkq) * a.R + r);
+    // Small operands of a chunk -- the W4 rows of its 16 channels (the W4^T fragment of the dG product, and w4[c][r] for dalpha)
+    // and b4[c] -- travel by LDS-DMA beside the dE chunk, into the same double-buffered scheme.  vmcnt retires IN ORDER, so a
+    // plain load consumed inside the loop body would wait for the whole DMA chunk issued in front of it (and hipcc sinks plain
+    // loads below the DMA at will): that serialised the prefetch (tools/de_tail_phases.py: 70 % of a chunk's time).  A first fix
+    // -- inline-asm loads one chunk ahead -- was WRONG: the compiler does not know such registers are pending and may copy them
+    // (loop-carried values, allocation) before the wait; it showed as garbage dp / dq of single (n, subset) pairs once four models'
+    // kernels ran side by side under one HIP graph.  Through LDS every consumer is an ordinary ds_read after the barrier.
+    auto issue_small = [&](int c0, int buf) {
+        if (wave == NW - 1) {                                       // the wave with no dE piece of its own (25 pieces over 8 waves)
+            float* dst = W4s + buf * (WQ + 256);
+            const float* g4 = a.w4 + ((long long)s * a.Cout + c0) * a.R;
+            for (int piece = 0; piece < WQ / 256; ++piece) {
+                int f = piece * 256 + lane * 4;
+                if (f > 16 * a.R - 4) f = 16 * a.R - 4;
+                __builtin_amdgcn_global_load_lds((de_gptr)(g4 + f), (de_lptr)(dst + piece * 256), 16, 0, 0);
             }
-#pragma unroll
-        for (int i = 0; i < NFL; ++i) {
-            const int e = tid + i * NT, c = (e / (RT * 16)) & 15, r = e - (e / (RT * 16)) * (RT * 16);
-            gload(w4n[i], a.w4 + ((long long)s * a.Cout + c0 + c) * a.R + (r < a.R ? r : 0));
+            const int fb = lane < 4 ? lane * 4 : 12;
+            __builtin_amdgcn_global_load_lds((de_gptr)(a.b4 + s * a.Cout + c0 + fb), (de_lptr)(dst + WQ), 16, 0, 0);
         }
-        gload(b4n, a.b4 + s * a.Cout + c0 + dbc);
     };
-    fetch_next(cbeg);
-#pragma unroll
-    for (int i = 0; i < NFL; ++i) { w4p[i] = 0.f; w4c[i] = 0.f; }
+    issue_small(cbeg, 0);
+    constexpr int NFL = (16 * RT * 16 + NT - 1) / NT;               // flush items per thread (1)
+    static_assert(NFL == 1, "one flush item per thread");
+    const int dbc = (tid >> 4) & 15;                                // this thread's channel in the db4 pass
+    float aw[RT][4];
     // the partial dW4 tiles of one chunk -> global (fixed order over the waves)
-    auto flush_red = [&](int c0, const float* rb, const float (&w)[NFL]) {
+    const int fe_c = tid / (RT * 16), fe_r = tid - fe_c * (RT * 16);
+    const bool fe_ok = tid < 16 * RT * 16 && fe_r < a.R;            // this thread's entry (channel, r) of a chunk's dW4 tile
+    float w4own = 0.f, w4prev = 0.f;                                // w4[c][r] of that entry: this chunk's, the previous chunk's
+    auto flush_red = [&](int c0, const float* rb, float w4v) {
+        if (fe_ok) {
+            float t = 0.f;
 #pragma unroll
-        for (int i = 0; i < NFL; ++i) {
-            const int e = tid + i * NT;
-            const int c = e / (RT * 16), r = e - c * (RT * 16);
-            if (e < 16 * RT * 16 && r < a.R) {
-                float t = 0.f;
-#pragma unroll
-                for (int wv = 0; wv < NW; ++wv) t += rb[(wv * 16 + c) * (RT * 16) + r];
-                const long long wi = ((long long)s * a.Cout + c0 + c) * a.R + r;
-                a.dw4_part[(long long)n * a.S * a.Cout * a.R + wi] = alpha * t;
-                dalpha_acc = fmaf(w[i], t, dalpha_acc);
-            }
+            for (int wv = 0; wv < NW; ++wv) t += rb[(wv * 16 + fe_c) * (RT * 16) + fe_r];
+            const long long wi = ((long long)s * a.Cout + c0 + fe_c) * a.R + fe_r;
+            a.dw4_part[(long long)n * a.S * a.Cout * a.R + wi] = alpha * t;
+            dalpha_acc = fmaf(w4v, t, dalpha_acc);
         }
     };
 
@@ -333,19 +331,22 @@ __global__ __launch_bounds__(512) void ctrgc_de_tail_kernel(const TailArgs a) {
         const float* DE = DEs + (ci & 1) * CHP;
         float* rb = red + (NRED == 2 ? (ci & 1) : 0) * NW * 16 * RT * 16;
         TG_T(ta);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of chunk c0 and its small operands have landed
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4) aw[rt][k4] = rt * 16 + mj < a.R ? awn[rt][k4] : 0.f;
-#pragma unroll
-        for (int i = 0; i < NFL; ++i) { w4p[i] = w4c[i]; w4c[i] = w4n[i]; }
-        b4c = b4n;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of chunk c0 (dE and small operands) have landed
         TG_T(tb); TG_ACC(1, tb - ta);
         __syncthreads();                                           // everyone's have; chunk c0 - 16 is consumed (and D is filled)
         TG_T(tc); TG_ACC(2, tc - tb);
-        if (c0 + 16 < cend) { fetch_next(c0 + 16); issue(c0 + 16, (ci + 1) & 1); }
-        if (NRED == 2 && ci > 0) flush_red(c0 - 16, red + ((ci - 1) & 1) * NW * 16 * RT * 16, w4p);
+        if (c0 + 16 < cend) { issue_small(c0 + 16, (ci + 1) & 1); issue(c0 + 16, (ci + 1) & 1); }
+        const float* W4c = W4s + (ci & 1) * (WQ + 256);           // this chunk's W4 rows [16][R] and b4 [16]
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) aw[rt][k4] = rt * 16 + mj < a.R ? W4c[(k4 * 4 + mkq) * a.R + rt * 16 + mj] : 0.f;
+        const float b4c = W4c[WQ + dbc];
+        // (the previous chunk's W4 rows sit in the buffer the DMA just issued is overwriting: its entry for the dalpha sum was taken
+        // at that chunk's own iteration)
+        w4prev = w4own;
+        w4own = fe_ok ? W4c[fe_c * a.R + fe_r] : 0.f;
+        if (NRED == 2 && ci > 0) flush_red(c0 - 16, red + ((ci - 1) & 1) * NW * 16 * RT * 16, w4prev);
         TG_T(td); TG_ACC(3, td - tc);
         // dG[r][uv] += sum_c W4[c][r] dE[c][uv]
 #pragma unroll
@@ -411,13 +412,13 @@ __global__ __launch_bounds__(512) void ctrgc_de_tail_kernel(const TailArgs a) {
         TG_T(th); TG_ACC(7, th - tg);
         if (NRED == 1) {
             __syncthreads();
-            flush_red(c0, rb, w4c);
+            flush_red(c0, rb, w4own);
         }
         TG_T(ti); TG_ACC(10, ti - th);
     }
     if (NRED == 2) {
         __syncthreads();
-        flush_red(cend - 16, red + ((ci - 1) & 1) * NW * 16 * RT * 16, w4c);   // (no rotation after the last chunk)
+        flush_red(cend - 16, red + ((ci - 1) & 1) * NW * 16 * RT * 16, w4own);
     }
     TG_T(tz0);
 #pragma unroll
@@ -694,7 +695,8 @@ void allow_lds(K kernel, size_t lds, tg_devmask* done) {       // once per insta
 template <int V>
 size_t tail_lds(int R, int RT, bool dbr) {
     const size_t chp = ((size_t)16 * V * V + 255) & ~(size_t)255;
-    return sizeof(float) * (2 * chp + (size_t)(dbr ? 2 : 1) * 8 * 16 * RT * 16 + (size_t)R * tail_pitch(V * V) + 2 * (size_t)R * V);
+    const size_t wq = ((size_t)16 * R + 255) & ~(size_t)255;
+    return sizeof(float) * (2 * chp + (size_t)(dbr ? 2 : 1) * 8 * 16 * RT * 16 + (size_t)R * tail_pitch(V * V) + ((2 * (size_t)R * V + 3) & ~(size_t)3) + 2 * (wq + 256));
 }
 
 template <int V>
@@ -756,13 +758,17 @@ extern "C" int tamgcn_ctrgc_bwd_de_tail(const tamgcn_ctrgc_desc* d, const float*
     a.dA_part = dA_part; a.dw4_part = dw4_part; a.db4_part = db4_part; a.dalpha_part = dalpha_part; a.dpq = dpq;
     const int rt = d->R <= 16 ? 1 : 2;
     bool launched = false;
-    // V = 20: the LDS-DMA form at R <= 8 (73 KB, one partial buffer: two workgroups per CU) and at R > 16 (140 KB, everything
+    // V = 20: the LDS-DMA form at R <= 8 (75 KB, one partial buffer: two workgroups per CU) and at R > 16 (145 KB, everything
     // double-buffered, one per CU either way); 8 < R <= 16 stays on the register-staged form, whose 62 KB put two workgroups
-    // on a CU where the DMA form's 95 KB put one (measured: 238 vs 254 us per dE chain at 128 channels)
-    const bool dbr = d->R > 16, reg16 = d->V == 20 && d->R > 8 && d->R <= 16;
-    if (reg16) { DE_TAIL_REG_CASE(20, 1) }
-    else DE_TAIL_CASE(20, 1, false) else DE_TAIL_CASE(20, 2, true)
-    else DE_TAIL_REG_CASE(25, 1) else DE_TAIL_REG_CASE(25, 2)
+    // on a CU where the DMA form's 95 KB put one (measured: 238 vs 254 us per dE chain at 128 channels).  DMA pieces are 16 bytes
+    // per lane: operands that are not 16-byte aligned take the register-staged form too.
+    const bool al16 = (((uintptr_t)dE | (uintptr_t)d->w4 | (uintptr_t)d->b4) & 15) == 0;
+    const bool dbr = d->R > 16, reg = d->V != 20 || !al16 || (d->R > 8 && d->R <= 16);
+    if (reg) {
+        DE_TAIL_REG_CASE(20, 1) else DE_TAIL_REG_CASE(20, 2) else DE_TAIL_REG_CASE(25, 1) else DE_TAIL_REG_CASE(25, 2)
+    } else {
+        DE_TAIL_CASE(20, 1, false) else DE_TAIL_CASE(20, 2, true)
+    }
     TG_CHECK(launched, "tamgcn_ctrgc_bwd_de_tail: unsupported V=%d (V in {20,25})", d->V);
     TG_LAUNCH_CHECK("tamgcn_ctrgc_bwd_de_tail");
     return 0;
