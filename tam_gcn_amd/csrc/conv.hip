@@ -412,9 +412,13 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel_vec(const ConvArgs a) {
     }
     float4 r1[NPF], r2[NPF];
     const bool has2 = a.src.x2 != nullptr;
-    // weight tile of a 1x1 conv (BMT*BKV floats) is prefetched as well: NAF values per thread
-    constexpr int NAF = (BMT * BKV + NTHREADS - 1) / NTHREADS;
-    const bool apf = a.KT == 1;
+    // the weight tile of a chunk (KT*BMT*BKV floats) is prefetched as well: NAF values per thread.  Round 3: for the k x 1
+    // kernels too (up to KTP = 5 taps on the BKV = 16 variants, which is where the temporal branches run): their tile used to
+    // be fetched by a load-store loop inside the K loop -- 5 to 20 dependent L2 round trips per chunk, which is what the
+    // k = 5 launches spent most of their 33..153 us on (roofs 7..25 us, profiles/r03_roofline_table_nucla.txt)
+    constexpr int KTP = BKV == 16 ? 5 : 1;
+    constexpr int NAF = (KTP * BMT * BKV + NTHREADS - 1) / NTHREADS;
+    const bool apf = a.KT <= KTP;
     float wr[NAF];
     auto prefetch = [&](int k0) {
 #pragma unroll
@@ -431,10 +435,12 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel_vec(const ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < NAF; ++i) {
                 int e = tid + i * NTHREADS;
+                const int tap = e / (BMT * BKV);
+                e -= tap * (BMT * BKV);
                 int ii, kk;
                 if (a.wmode == 0) { kk = e % BKV; ii = e / BKV; } else { ii = e % BMT; kk = e / BMT; }
                 int m = m0 + ii, k = k0 + kk;
-                wr[i] = (e < BMT * BKV && m < a.M && k < a.K) ? a.w[m * a.ws_m + k * a.ws_k + a.w_off] : 0.f;
+                wr[i] = (tap < a.KT && m < a.M && k < a.K) ? a.w[m * a.ws_m + k * a.ws_k + tap * a.ws_t + a.w_off] : 0.f;
             }
         }
     };
@@ -457,9 +463,11 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel_vec(const ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < NAF; ++i) {
                 int e = tid + i * NTHREADS;
+                const int tap = e / (BMT * BKV);
+                e -= tap * (BMT * BKV);
                 int ii, kk;
                 if (a.wmode == 0) { kk = e % BKV; ii = e / BKV; } else { ii = e % BMT; kk = e / BMT; }
-                if (e < BMT * BKV) As[ii * BKVP + kk] = wr[i];
+                if (tap < a.KT) As[(tap * BMT + ii) * BKVP + kk] = wr[i];
             }
         } else if (a.wmode == 0) {                     // weight rows contiguous along k
             for (int e = tid; e < nA; e += NTHREADS) {
