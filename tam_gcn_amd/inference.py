@@ -17,11 +17,19 @@ __all__ = ['GraphedForward']
 
 
 class GraphedForward:
-    def __init__(self, model, method='forward', max_shapes=8):
+    """split (default 1): eval-mode BatchNorm uses the running statistics, so a batch may be cut into `split` slices that run
+    side by side on their own HIP streams inside the graph (functional.model_stream) and land in one output tensor -- kernels that
+    wait for operands leave room that another slice's kernels fill (four models side by side in one graph run 23 % faster than
+    one after the other: DESIGN.md §3 lessons).  Measured on the N-UCLA model: 256 clips 9.36 -> 8.74 ms, 512 clips 17.8 -> 16.5 ms
+    with split = 4.  Slices are kept at >= 64 clips (smaller ones would take the latency-oriented f2 kernels, which lose on
+    throughput); only tensor-valued methods (forward)."""
+
+    def __init__(self, model, method='forward', max_shapes=8, split=1):
         if model.training:
             raise ValueError('GraphedForward: put the model in eval() mode first (train mode updates running statistics)')
-        self.model, self.method, self.max_shapes = model, method, max_shapes
+        self.model, self.method, self.max_shapes, self.split = model, method, max_shapes, int(split)
         self._graphs = {}
+        self._streams = None
 
     def reset(self):
         self._graphs.clear()
@@ -37,8 +45,25 @@ class GraphedForward:
                     fn(static_in)
             torch.cuda.current_stream(x.device).wait_stream(s)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                out = fn(static_in)
+            nsl = max(1, min(self.split, x.shape[0] // 64))
+            if nsl > 1:
+                from . import functional as Fn
+                if self._streams is None:
+                    self._streams = [torch.cuda.Stream(device=x.device) for _ in range(self.split)]
+                parts = static_in.chunk(nsl)
+                with torch.cuda.graph(g):
+                    cur = torch.cuda.current_stream(x.device)
+                    outs = []
+                    for st, xp in zip(self._streams, parts):
+                        st.wait_stream(cur)
+                        with Fn.model_stream(st):
+                            outs.append(fn(xp))
+                    for st in self._streams[:len(parts)]:
+                        cur.wait_stream(st)
+                    out = torch.cat(outs)
+            else:
+                with torch.cuda.graph(g):
+                    out = fn(static_in)
         # The graph reads the eval path's folded BatchNorm coefficients through their pointers, and those tensors are
         # owned by the per-module caches (functional._eval_cached): an eager forward after a parameter change evicts
         # them.  This entry keeps them alive, so a replay without reset() reads stale coefficients, never freed memory.

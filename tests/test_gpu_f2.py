@@ -205,6 +205,23 @@ def test_block_is_a_registered_operator():
     assert float((ref[1].sum(1) - ref[0].sum(2) / 2).abs().max()) <= 1e-5 * float(ref[0].abs().max()) * 6     # xpart = frame sums of out
 
 
+def test_graphed_forward_batch_slices_on_streams():
+    """GraphedForward(split=2): the eval batch in two slices on two streams inside one graph equals the whole-batch forward
+    (same kernels on 64-clip slices: to rounding of nothing -- eval BatchNorm is per element) and replays identically."""
+    from tam_gcn_amd.inference import GraphedForward
+    m, _ = _model()
+    m = m.to(DEV).eval()
+    x = make_input((128, 3, 32, 20, 1), seed=2).to(DEV)
+    with torch.no_grad():
+        ref = m(x)
+    fast = GraphedForward(m, split=2)
+    a = fast(x).clone()
+    b = fast(x).clone()
+    assert torch.equal(a, b)
+    assert float((a - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    assert GraphedForward(m, split=4)(x[:100]).shape == ref[:100].shape       # 100 clips: one slice of >= 64, i.e. unsplit
+
+
 def test_engine_argument_guards():
     m, _ = _model()
     with pytest.raises(ValueError):

@@ -44,4 +44,16 @@ for B in ([int(v) for v in args] or (1, 16, 256)):
             g.replay()
         torch.cuda.synchronize()
         graph = (time.perf_counter() - t0) / n
-    print(f'batch {B:4d}: eager {eager * 1e3:7.2f} ms ({B / eager:9.0f} clips/s)   hip graph {graph * 1e3:7.2f} ms ({B / graph:9.0f} clips/s)', flush=True)
+        extra = ''
+        for sp in ([int(v) for v in os.environ.get('INFER_SPLITS', '').split(',') if v] if B >= 16 else []):
+            from tam_gcn_amd.inference import GraphedForward
+            fast = GraphedForward(m, split=sp)
+            ys = fast(x); torch.cuda.synchronize()
+            assert float((ys - y).abs().max()) <= 1e-4 * float(y.abs().max()), float((ys - y).abs().max())   # (slices of <= 32 clips take the f2 kernels)
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fast(x)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n
+            extra += f'   split {sp}: {dt * 1e3:6.2f} ms ({B / dt:8.0f} clips/s)'
+    print(f'batch {B:4d}: eager {eager * 1e3:7.2f} ms ({B / eager:9.0f} clips/s)   hip graph {graph * 1e3:7.2f} ms ({B / graph:9.0f} clips/s)' + extra, flush=True)
