@@ -13,6 +13,7 @@
 // *input* is fused into the LDS fill, BatchNorm moment accumulation of the
 // *output* into the epilogue (per-block partial sums, no atomics).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -1106,6 +1107,10 @@ static int plan_conv(const tamgcn_conv_desc* d, ConvPlan* p) {
         }
         // output-channel tile: 16*mt rows, mt chosen so that M splits without a half-empty tile
         p->mt = d->M <= 16 ? 1 : d->M <= 32 ? 2 : (d->M % 64 == 0 ? 4 : (d->M % 48 == 0 ? 3 : 4));
+        // k x 1 kernels: a 64-row tile is 1600 dependent MFMAs per wave and one workgroup per CU (the launch is a chain of
+        // latencies, not a throughput problem: 52 us for ONE workgroup at C = 64, tools/tconv_scaling.py); two 32-row tiles per
+        // 64 channels put two workgroups on a CU: 52 -> 35 us per chain, 57.5 -> 54.5 us at 256 clips, +0.6 % on the step
+        if (d->KT > 1 && p->mt == 4) p->mt = 2;
         p->cwt = p->CW <= 3 ? 3 : 5;
         if (p->vec) {                                       // staged epilogue needs >= 16 rows of (cwt*64+4) floats
             size_t avail = (((size_t)d->KT * p->mt * 16 * (p->bk + 2) + 3) & ~(size_t)3) + (size_t)p->bk * pitch;
