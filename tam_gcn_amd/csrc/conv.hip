@@ -856,6 +856,7 @@ __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs
     float* Ss = cf + 3 * a.K;                                     // [2][4*BM] row moments
     float* Bc = Ss + 2 * 4 * BM;                                  // [128] per-row constant of the linear prologue
 
+    TG_T(tt0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kq = lane >> 4, wm = wave >> 2, wn = wave & 3;
     const int V = a.V, K = a.K, LB = a.LB;
@@ -973,10 +974,15 @@ __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs
     __syncthreads();
     const int nch = nsrc * nchk;
     issue(0);
+    TG_T(tt1); TG_ACC(0, tt1 - tt0);
     for (int c = 0; c < nch; ++c) {
+        TG_T(ta);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TG_T(tb); TG_ACC(2, tb - ta);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        TG_T(tc); TG_ACC(4, tc - tb);
         if (c + 1 < nch) issue(c + 1);
+        TG_T(td); TG_ACC(5, td - tc);
         const float* st = smem + (c % GS_NST) * STG;
         const float* As = st + BK * G_PBMAX;
         const int k0 = (c % nchk) * BK;
@@ -1007,6 +1013,7 @@ __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs
             }
             split_bf16x8(v0, v1, ah[mt], al[mt]);
         }
+        TG_T(te); TG_ACC(3, te - td);
 #pragma unroll
         for (int cc = 0; cc < G_CWT; ++cc) {
             f32x4 v0, v1;
@@ -1017,7 +1024,9 @@ __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs
 #pragma unroll
             for (int mt = 0; mt < GS_MT; ++mt) acc[mt][cc] = mfma_split(ah[mt], al[mt], bh, bl, acc[mt][cc]);
         }
+        TG_T(tf); TG_ACC(6, tf - te);
     }
+    TG_T(tg0);
 
     // ---- staged epilogue: four passes of 32 rows.  The constant term W^T c0: sum over the four kq lanes of a row,
     // one column-wave per row group publishes it (Ss is free: this kernel produces no moments).
@@ -1059,6 +1068,7 @@ __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs
             if (m < a.M) a.stats_part[((long long)stt * a.stats_ctot + a.stats_coff + m) * a.nparts + g] = Ss[stt * 4 * BM + row];
         }
     }
+    TG_T(tg1); TG_ACC(7, tg1 - tg0); TG_ACC(8, tg1 - tt0); TG_ACC(9, 1);
 }
 
 template <int NSRC, int BK>
