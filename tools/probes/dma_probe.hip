@@ -90,5 +90,8 @@ int main() {
     run<3, 5, 2>(x, out, quarter, 0);   run<3, 5, 4>(x, out, quarter, 0);
     run<3, 3, 2>(x, out, quarter, 45 * 1024);               // one workgroup per CU
     run<3, 3, 4>(x, out, n, 0);                             // 1 GB working set
+    // the split data-gradient GEMM's shape: two stages of 57 KB (seven pieces per wave), one workgroup per CU
+    run<2, 7>(x, out, quarter, 0);      run<2, 7, 4>(x, out, quarter, 0);   run<2, 7, 8>(x, out, quarter, 0);   run<2, 7, 16>(x, out, quarter, 0);
+    run<2, 5>(x, out, quarter, 0);      run<2, 5, 8>(x, out, quarter, 0);   run<2, 3>(x, out, quarter, 0);      run<2, 3, 8>(x, out, quarter, 0);
     return 0;
 }
