@@ -125,10 +125,17 @@ class FusedEval:
         self._epochs = [Fn._bn_epoch(m) for m in model.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
         self._key = None
         self._blocks = None
+        self._mods = None
 
     # ---- folded parameters, re-derived when any parameter or buffer changed ------------------------------------------
     def _state_key(self):
-        return tuple(t._version for t in self._watch) + tuple(e[0] for e in self._epochs) + (self._watch[0].data_ptr(),)
+        m = self.model
+        mods = tuple(id(getattr(m, f'l{i}', None)) for i in range(1, 11)) + (id(m.data_bn), id(m.fc))
+        if mods != self._mods:                                     # a block was replaced: re-collect what to watch
+            self._mods = mods
+            self._watch = list(m.parameters()) + list(m.buffers())
+            self._epochs = [Fn._bn_epoch(b) for b in m.modules() if isinstance(b, torch.nn.modules.batchnorm._BatchNorm)]
+        return tuple(t._version for t in self._watch) + tuple(e[0] for e in self._epochs) + (self._watch[0].data_ptr(), mods)
 
     def _packed(self, device):
         key = self._state_key()
