@@ -202,17 +202,22 @@ def roofline_of(agg):
                       mfma_dtype='bf16 x3 (two-term split of fp32 operands)' if split else 'f32', traffic=traffic)
         if not split:
             common['mfma_f32_frac'] = fl / F32_MFMA_PEAK
+        # achieved / peak / frac are against the NEARER of the two a-priori roofs (the one the launch's algorithmic bytes and
+        # flops say binds).  A launch that reaches less than half of BOTH is bound by neither: DESIGN.md section 3 (ring probe,
+        # phase stamps) shows those kernels limited by instruction issue and per-chunk latency, and the line says so.
         if t_mfma > t_hbm:
             r = dict(bound='mfma', achieved=fl / 1e12, peak=mpeak / 1e12, unit='TFLOP/s', frac=fl / mpeak)
         else:
             r = dict(bound='hbm', achieved=bw / 1e9, peak=HBM_PEAK / 1e9, unit='GB/s', frac=bw / HBM_PEAK)
+        r['nearest_roof'] = r['bound']
+        if max(bw / HBM_PEAK, fl / mpeak) < 0.5:
+            r['bound'] = 'issue'
         r.update(common)
         return r
 
-    # `roofline` = the kernel symbol with the largest share of the step, against ITS binding roof.  Since round 3 that is the
-    # split-bf16 data-gradient GEMM (7.1-7.9 ms per two instrumented steps against the fused CTRGC forward's 6.6);
-    # `north_star_kernel` carries the same object for the fused CTRGC forward -- the kernel BASELINE.json's north_star names and
-    # earlier rounds reported here -- whatever its rank, and roofline.top3 lists the three leaders.
+    # `roofline` = the kernel symbol with the largest share of the step IN THE HEADLINE'S GEMM MODE (the instrumented steps
+    # run in that mode), against its nearer roof; `north_star_kernel` carries the same object for the fused CTRGC forward --
+    # the kernel BASELINE.json's north_star names -- whatever its rank, and roofline.top3 lists the three leaders.
     r = describe(order[0])
     ns = next((k for k in order if k.startswith('ctrgc_fwd')), None)
     r['north_star_kernel'] = describe(ns) if ns else None
@@ -223,7 +228,8 @@ def roofline_of(agg):
         # the split GEMMs spend three bf16 MFMAs per fp32 product: their matrix roof is the dense bf16 peak / 3
         peak = BF16_MFMA_PEAK / 3.0 if ('split_kernel<2' in k or ', split,' in k) else F32_MFMA_PEAK
         fh, fm = v['bytes'] / sk / HBM_PEAK, v['flops'] / sk / peak
-        top.append(dict(kernel=k, ms=round(v['ms'], 3), launches=v['calls'], bound='mfma' if v['flops'] / peak > v['bytes'] / HBM_PEAK else 'hbm',
+        near = 'mfma' if v['flops'] / peak > v['bytes'] / HBM_PEAK else 'hbm'
+        top.append(dict(kernel=k, ms=round(v['ms'], 3), launches=v['calls'], bound=near if max(fh, fm) >= 0.5 else 'issue', nearest_roof=near,
                         hbm_frac=round(fh, 4), mfma_frac=round(fm, 4), mfma_peak_tflops=round(peak / 1e12, 1)))
     r['top3'] = top
     shares = {k: round(v['ms'], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])}
@@ -257,9 +263,9 @@ _T0 = time.perf_counter()
 
 def cpu_baseline():
     """The oracle (kind 'port': our stock-PyTorch restatement, pinned to the reference by tests/golden) on the host
-    cores, forward + CE + backward (optimizer step excluded).  `value` is the leg with the GPU line's
-    own workload (batch 256, T = 64); the reference's batch size (16, config/nucla/gcn.yaml:37) and real clip length
-    (T = 52, feeder/feeder_nucla_gcn.py:26) are reported beside it.  Bounded: fixed step counts, ~1.5 min on a 16-thread share."""
+    cores, forward + CE + backward (optimizer step excluded).  Legs: the reference's batch size (16,
+    config/nucla/gcn.yaml:37) at T = 64 and at its real clip length (T = 52, feeder/feeder_nucla_gcn.py:26), and the GPU
+    line's own batch (256, T = 64); `value` is the fastest T = 64 leg.  Bounded: fixed step counts, ~1.5 min on a 16-thread share."""
     from oracle import ctrgcn_oracle as O
     from tam_gcn_amd.models.ctrgcn import Model
     cores = host_cores()
@@ -292,10 +298,12 @@ def cpu_baseline():
     # 3 warm-up + >= 5 timed steps at the reference's batch size; the bench workload's own batch (256)
     # costs ~17 s per step on a 16-thread share, so it gets 2 warm-up + 3 timed (what bounds this function's run time)
     legs = [leg(16, T_FRAMES, 3, 8), leg(16, 52, 3, 8), leg(PER_GPU_BATCH, T_FRAMES, 2, 3)]
-    main_leg = legs[2]
+    # `value` = the CPU's BEST leg at the GPU line's clip length (T = 64): the fair figure to set a GPU rate against (the
+    # batch-256 leg is ~5x slower per clip on the host: cache footprint); every leg stays in `legs`
+    main_leg = max((l for l in legs if l['T'] == T_FRAMES), key=lambda l: l['clips_per_s'])
     return dict(value=main_leg['clips_per_s'], unit='clips/s', cores=torch.get_num_threads(), kind='port',
-                sample=f"{main_leg['steps']} steps of batch {PER_GPU_BATCH} (T=64,V=20) fwd+CE+bwd after {main_leg['warmup']} warm-up, "
-                       f"{main_leg['seconds']}s; optimizer step excluded",
+                sample=f"best T=64 leg: {main_leg['steps']} steps of batch {main_leg['batch']} (T=64,V=20) fwd+CE+bwd after "
+                       f"{main_leg['warmup']} warm-up, {main_leg['seconds']}s; optimizer step excluded; all legs in `legs`",
                 legs=legs)
 
 
@@ -340,6 +348,12 @@ def main():
                          'inside the HIP graph or eagerly: 4 (default) or 2 = that many at a time, 0 or 1 = one after the other on the '
                          'current stream.  Bit-identical to the one-stream step either way (tests/test_gpu_configs.py)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--gemm-mode', choices=('exact', 'split'), default='exact',
+                    help="arithmetic of the headline step: 'exact' (default) = the reference's own fp32 in every GEMM "
+                         "(tamgcn_set_split_mode(0)); 'split' = backward weight-gradient and C>=128 data-gradient GEMMs as a 2-term "
+                         "bf16 split (mode 1; the line's dtype says so) -- for profiling that mode on its own")
+    ap.add_argument('--single-mode', action='store_true',
+                    help='do not measure the other GEMM mode beside the headline (one rocprofv3 stats file per mode: tools/profile_round.sh)')
     args = ap.parse_args()
 
     # TAMGCN_BENCH_REHEARSAL=1: the multi-rank CONTROL FLOW (spawn, rendezvous, broadcast, step, one flat all-reduce, flat SGD,
@@ -378,6 +392,7 @@ def main():
         from tam_gcn_amd import _lib
         probe = _Probe(_lib.load())
         _lib._lib = probe                                 # every ABI launch goes through the probe
+        probe._lib.tamgcn_set_split_mode(0 if args.gemm_mode == 'exact' else 1)
 
     four = args.config == '4stream'
     B = args.batch or (128 if four else PER_GPU_BATCH)
@@ -508,15 +523,15 @@ def main():
     _log(f'timed {args.steps} steps in {dt:.3f}s ({mode})')
 
     out = None
-    roof, shares, layer_rows, ms_exact = None, {}, [], None
-    split = 1
+    roof, shares, layer_rows, ms_other = None, {}, [], None
+    split = 0
     if not rehearsal:
-        # the same step with EVERY GEMM on the exact fp32-input MFMA (mode 0), re-captured, a few replays: reported beside
-        # the headline number, whose backward GEMMs use the 2-term bf16 split by default
+        # the same step in the OTHER GEMM mode, re-captured, a few replays: reported beside the headline (exact fp32 by
+        # default; the other mode is then the 2-term bf16 split in the backward GEMMs) under its own keys
         lib = probe._lib
         split = lib.tamgcn_get_split_mode()
-        if split != 0 and world == 1:
-            lib.tamgcn_set_split_mode(0)
+        if world == 1 and not args.single_mode:
+            lib.tamgcn_set_split_mode(1 - split)
             try:
                 step0 = eager_step
                 if mode == 'hipgraph':
@@ -536,10 +551,10 @@ def main():
                 for _ in range(k0):
                     step0()
                 torch.cuda.synchronize()
-                ms_exact = 1e3 * (time.perf_counter() - t0) / k0
+                ms_other = 1e3 * (time.perf_counter() - t0) / k0
             finally:
                 lib.tamgcn_set_split_mode(split)
-            _log(f'exact-fp32 (mode 0) step: {ms_exact:.2f} ms')
+            _log(f'GEMM mode {1 - split} step: {ms_other:.2f} ms')
     if not rehearsal:
         # Per-kernel durations for the roofline: the same step, launched eagerly on ONE stream, HIP events around every ABI
         # launch.  (With the side streams on, kernels overlap and an event pair measures the overlap, not the kernel:
@@ -559,17 +574,20 @@ def main():
                        'timed on rank 0 of the N = 1 run only (the host cores are shared by the N ranks here)')
         else:
             cpu, cpu_why = cpu_baseline(), None
-        split = str(split)
         clips = world * B * args.steps * len(streams)
+        other = {0: 'exact_f32', 1: 'split_bf16'}[1 - split]
+        DTYPES = {0: 'f32 (exact fp32-input MFMA v_mfma_f32_16x16x4_f32 in every GEMM, forward and backward: the reference\'s arithmetic)',
+                  1: 'f32 storage; fwd GEMMs exact fp32-input MFMA; bwd weight-gradient and C>=128 data-gradient GEMMs 2-term '
+                     'bf16 split = 3 bf16 MFMAs, ~4.5e-6 rel. error (TAMGCN_SPLIT_BF16=1, opt-in, NOT the reference\'s precision)'}
         out = {
             'metric': 'skeleton clips/sec (fwd+CE+bwd+grad all-reduce+SGD step), N-UCLA 20-joint x 64-frame',
             'value': None if rehearsal else clips / dt, 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'ms_per_step_exact_f32': ms_exact,
-            'value_exact_f32': None if (ms_exact is None or rehearsal) else world * B * len(streams) / (ms_exact * 1e-3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None,
-            'dtype': {'0': 'f32 (exact fp32-input MFMA in every GEMM, TAMGCN_SPLIT_BF16=0)',
-                      '1': 'f32 (fwd GEMMs exact fp32-input MFMA; bwd weight-gradient and C>=128 data-gradient GEMMs 2-term '
-                           'bf16 split = 3 bf16 MFMAs, ~4.5e-6 rel. error, TAMGCN_SPLIT_BF16=1)'}.get(split, split),
+            'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPES[split], 'gemm_mode': split,
+            # the other GEMM mode, measured in the same run (null with --single-mode or N > 1): never the headline
+            f'ms_per_step_{other}': ms_other,
+            f'value_{other}': None if (ms_other is None or rehearsal) else world * B * len(streams) / (ms_other * 1e-3),
+            f'dtype_{other}': DTYPES[1 - split],
             'data': 'synthetic',
             'config': {'workload': (f'N-UCLA 4-stream (joint/bone/motion/bone-motion derived on GPU), 4 x models.ctrgcn.Model, '
                                     f'{B} clips/GPU/stream x (3,64,20,1), ONE {arena.total * 4 / 1e6:.1f} MB gradient bucket' if four else

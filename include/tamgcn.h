@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TAMGCN_VERSION 310          /* round 3: bumped on every change of a struct layout, signature or documented semantics */
+#define TAMGCN_VERSION 400          /* round 4: bumped on every change of a struct layout, signature or documented semantics */
 #define TAMGCN_MAX_SUBSETS 3
 #define TAMGCN_MAX_V 32             /* joints supported by the LDS-resident CTRGC tiles (V in {20, 25}); V in {32, 64}: tamgcn_ctrgc_tiled_* */
 
@@ -57,7 +57,8 @@ const char* tamgcn_last_error(void);
 /* symbol (template arguments included) of the kernel the calling thread's last ABI call launched;
  * lets a profiler attribute HIP-event timings to the rows of a rocprofv3 kernel trace */
 const char* tamgcn_last_kernel(void);
-/* GEMM arithmetic policy (process-wide; initial value from the environment variable TAMGCN_SPLIT_BF16, default 1):
+/* GEMM arithmetic policy (process-wide; initial value from the environment variable TAMGCN_SPLIT_BF16, default 0 =
+ * the reference's own arithmetic; 1 is an opt-in):
  *   0  exact fp32-input MFMA (v_mfma_f32_16x16x4_f32) in every GEMM;
  *   1  as 0 in the forward; weight-gradient GEMMs and the data-gradient GEMMs into >= 128 channels run as a 2-term
  *      bf16 split (three v_mfma_f32_16x16x32_bf16, ~4.5e-6 relative error): their results never feed an activation.

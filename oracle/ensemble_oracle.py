@@ -6,10 +6,12 @@ score-level ensemble.
     fuse_softmax   ensemble/ensemble_ctrgcn_resnet_eval.py:99-108 -- scipy.special.softmax(axis=1) of each set, then a + alpha * b
     compute_accuracy   ensemble/ensemble_ctrgcn_resnet_eval.py:217-234
 
-Pinning: both scripts import modules that are absent here (seaborn, torchvision: ordinary ModuleNotFoundError) and the
-stored score pickles of the reference are not loadable with a non-executing loader, so there is no reference-generated
-fixture for these three formulas; the restatement calls the same numpy / scipy functions the scripts call.  Parity of this
-row is therefore "unpinned beyond the library calls" (DESIGN.md §4)."""
+Pinning: fuse_raw is PINNED -- tests/golden/make_golden_ensemble.py imports the reference's ensemble_resnet_ctrgcn.py (numpy,
+tqdm, pickle: all present here), runs its ensemble_fusion on synthetic label / score files and stores right_num / total_num,
+the printed accuracy and the skipped names (tests/golden/ensemble.npz; tests/test_ensemble_oracle.py).  fuse_softmax and
+compute_accuracy restate ensemble_ctrgcn_resnet_eval.py, whose module imports seaborn and torchvision (absent here: ordinary
+ModuleNotFoundError), so those two formulas stay "unpinned beyond the numpy / scipy calls they share with the script"
+(DESIGN.md section 4)."""
 import numpy as np
 from scipy.special import softmax
 

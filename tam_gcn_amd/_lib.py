@@ -149,7 +149,7 @@ class TamgcnLibraryError(RuntimeError):
 
 
 _lib = None
-ABI_VERSION = 310          # include/tamgcn.h TAMGCN_VERSION this binding's structs and signatures were written for
+ABI_VERSION = 400          # include/tamgcn.h TAMGCN_VERSION this binding's structs and signatures were written for
 
 
 def load():

@@ -14,7 +14,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 void tamgcn_set_error(const char* fmt, ...);
 void tamgcn_note_kernel(const char* fmt, ...);   // symbol of the kernel the last ABI call launched (per thread)
 int tamgcn_wgrad_taps(void);     // k x 1 weight gradients on the LDS-DMA kernel (TAMGCN_WGRAD_TAPS, default 1)
-int tamgcn_split_mode(void);     // TAMGCN_SPLIT_BF16: 0 = exact fp32-input MFMA everywhere; 1 (default) = two-term split-fp32 on the bf16 matrix
+int tamgcn_split_mode(void);     // TAMGCN_SPLIT_BF16: 0 (default) = exact fp32-input MFMA everywhere; 1 = two-term split-fp32 on the bf16 matrix
                                  // cores in the BACKWARD GEMMs (weight gradients, data gradients into >= 128 channels): their
                                  // results never decide a ReLU mask, the 4.5e-6 relative error stays a linear perturbation
 

@@ -32,8 +32,8 @@ int tamgcn_split_mode(void) {
     int mode = __atomic_load_n(&g_split_mode, __ATOMIC_RELAXED);
     if (mode < 0) {
         const char* e = getenv("TAMGCN_SPLIT_BF16");
-        mode = e ? atoi(e) : 1;
-        if (mode < 0 || mode > 1) mode = 1;
+        mode = e ? atoi(e) : 0;          // the reference is fp32 throughout: exact unless asked otherwise
+        if (mode < 0 || mode > 1) mode = 0;
         __atomic_store_n(&g_split_mode, mode, __ATOMIC_RELAXED);
     }
     return mode;

@@ -51,11 +51,13 @@ class ParamArena:
             off += p.numel()
         self.total = (off + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         self.flat = torch.zeros(self.total, device=dev, dtype=dt)
+        self.epoch = 0              # see state_version()
         with torch.no_grad():
             for p, o in zip(order, self.offsets):
                 v = self.flat[o:o + p.numel()].view(p.shape)
                 v.copy_(p.data)
                 p.data = v
+                p._tamgcn_arena = self          # the eval-mode caches key on state_version(): a write to `flat` does not bump p._version
         ptr = self.flat.untyped_storage().data_ptr()
 
         def clone_views(module, state, prefix, meta):
@@ -63,6 +65,18 @@ class ParamArena:
                 if isinstance(v, torch.Tensor) and v.untyped_storage().data_ptr() == ptr:
                     state[k] = v.clone()
         self._hook = model._register_state_dict_hook(clone_views)
+
+    def state_version(self):
+        """Changes whenever the parameter VALUES may have changed through the flat buffer.  ``p.data`` are views of ``flat``
+        taken under no_grad, so an in-place update of ``flat`` (flat SGD, a broadcast, a load into it) leaves every
+        ``p._version`` where it was; caches of folded parameters (f2.FusedEval, functional._eval_cached) add this pair to
+        their key.  ``flat._version`` sees eager in-place writes; ``epoch`` is bumped by SGDNesterov.step and
+        broadcast_state, and by ``touch()``, which a caller runs after anything Python cannot see: the REPLAY of a HIP
+        graph that holds the optimiser step executes no Python, so bump it after ``graph.replay()`` before an eval pass."""
+        return (self.flat._version, self.epoch)
+
+    def touch(self):
+        self.epoch += 1
 
     def intact(self):
         """False once something (``model.to``, manual re-assignment) has detached the parameters from the arena."""
@@ -145,6 +159,7 @@ def broadcast_state(module, src=0, group=None, arena=None):
         if not arena.intact():
             raise ValueError('broadcast_state: the ParamArena no longer backs the parameters')
         dist.broadcast(arena.flat, src=src, group=group)
+        arena.touch()
         inside = {id(p) for p in arena.params}
         rest = [t for t in rest if id(t) not in inside]
     by_type = {}
@@ -190,6 +205,7 @@ class SGDNesterov:
     def step(self):
         if self.arena is not None:
             p, g, buf = self.arena.flat, self.bucket.flat, self.flat_buf
+            self.arena.touch()
             d = torch.add(g, p, alpha=self.wd)                          # g + wd * p
             buf.mul_(self.momentum).add_(d)                             # buf = m*buf + d
             d.add_(buf, alpha=self.momentum)                            # d + m*buf (nesterov)

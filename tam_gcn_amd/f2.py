@@ -135,7 +135,15 @@ class FusedEval:
             self._mods = mods
             self._watch = list(m.parameters()) + list(m.buffers())
             self._epochs = [Fn._bn_epoch(b) for b in m.modules() if isinstance(b, torch.nn.modules.batchnorm._BatchNorm)]
-        return tuple(t._version for t in self._watch) + tuple(e[0] for e in self._epochs) + (self._watch[0].data_ptr(), mods)
+        # parameters inside a ParamArena are views of its flat buffer: an update of that buffer (flat SGD, a broadcast) does not
+        # bump their _version, the arena's own state_version() does
+        arenas = {}
+        for t in self._watch:
+            a = getattr(t, '_tamgcn_arena', None)
+            if a is not None:
+                arenas[id(a)] = a
+        return (tuple(t._version for t in self._watch) + tuple(e[0] for e in self._epochs) +
+                tuple(v for a in arenas.values() for v in a.state_version()) + (self._watch[0].data_ptr(), mods))
 
     def _packed(self, device):
         key = self._state_key()

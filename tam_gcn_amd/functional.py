@@ -224,6 +224,9 @@ EVAL_FUSED = os.environ.get('TAMGCN_EVAL_FUSED', '1') != '0'
 def _eval_cached(owner, tag, bns, build):
     """build() -> value, cached on nn.Module `owner` under `tag` while the tensors of the BN views `bns` are unchanged."""
     key = tuple((t.data_ptr(), t._version) for bn in bns for t in bn.tensors()) + tuple(_bn_epoch(bn.m)[0] for bn in bns)
+    arena = getattr(bns[0].w, '_tamgcn_arena', None) if bns else None      # weight / bias may be views of a ParamArena's flat
+    if arena is not None:                                                  # buffer: its updates do not bump their _version
+        key += arena.state_version()
     cache = owner.__dict__.setdefault('_tamgcn_eval_cache', {})
     hit = cache.get(tag)
     if hit is not None and hit[0] == key:

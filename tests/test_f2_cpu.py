@@ -83,3 +83,41 @@ def test_unsupported_geometries_are_refused_before_any_launch():
     blk = M.TCN_GCN_unit(60, 60, M.Model(**MODEL_CASES[1][1]).graph.A, kernel_size=5, dilations=[1, 2, 3])
     with pytest.raises(f2.Unsupported):                    # 3 temporal branches of 12 channels: not a multiple of 16
         f2._Block(blk, torch.device('cpu'))
+
+
+def test_state_key_sees_updates_through_a_param_arena():
+    """parameters inside a ParamArena are no_grad views of its flat buffer, so flat SGD / a flat broadcast /
+    a load into the buffer leave every p._version untouched.  The re-fold key must change all the same."""
+    from tam_gcn_amd.distributed import ParamArena, SGDNesterov
+    m = M.Model(**MODEL_CASES[1][1]).eval()
+    eng = f2.FusedEval(m)
+    k_plain = eng._state_key()
+    arena = ParamArena(m)
+    versions = [p._version for p in m.parameters()]
+    k0 = eng._state_key()
+    assert k0 != k_plain                                     # p.data was re-pointed at the arena
+    with torch.no_grad():
+        arena.flat.mul_(1.01)                                # e.g. a load into the flat buffer
+    assert [p._version for p in m.parameters()] == versions  # ... which the parameters' own counters do not see
+    k1 = eng._state_key()
+    assert k1 != k0
+    bucket = arena.grad_bucket()
+    for p in arena.params:
+        p.grad = torch.ones_like(p)
+    bucket.pack()
+    SGDNesterov(arena.params, lr=0.1, arena=arena, bucket=bucket).step()
+    k2 = eng._state_key()
+    assert k2 != k1
+    arena.touch()                                            # what a caller does after replaying a captured optimiser step
+    assert eng._state_key() != k2
+    # the general eval path's BatchNorm-coefficient cache (functional._eval_cached) keys on the arena too
+    from tam_gcn_amd import functional as Fn
+    bn = Fn.BN(m.l1.tcn1.branches[0][1])
+    built = []
+    Fn._eval_cached(m.l1.tcn1, 't', [bn], lambda: built.append(1))
+    Fn._eval_cached(m.l1.tcn1, 't', [bn], lambda: built.append(1))
+    assert len(built) == 1
+    with torch.no_grad():
+        arena.flat.add_(0.5)
+    Fn._eval_cached(m.l1.tcn1, 't', [bn], lambda: built.append(1))
+    assert len(built) == 2

@@ -1,5 +1,7 @@
-"""-m gpu: the score-level ensemble (tamgcn_score_fuse behind tam_gcn_amd.ensemble) against the numpy restatement of the
-reference's two ensemble scripts (oracle/ensemble_oracle.py; see its header for what pins it)."""
+"""-m gpu: the score-level ensemble (tamgcn_score_fuse behind tam_gcn_amd.ensemble) against (1) tests/golden/ensemble.npz = what
+the REFERENCE's own ensemble_fusion (ensemble/ensemble_resnet_ctrgcn.py:11-61) printed for synthetic label / score files
+(tests/golden/make_golden_ensemble.py), and (2) the numpy restatement oracle/ensemble_oracle.py, which
+tests/test_ensemble_oracle.py holds to the same fixture."""
 import numpy as np
 import pytest
 import torch
@@ -13,6 +15,24 @@ from tam_gcn_amd import ensemble as E              # noqa: E402
 def _scores(n, k, seed):
     rng = np.random.default_rng(seed)
     return (rng.standard_normal((n, k)) * 3).astype(np.float32)
+
+
+def test_raw_fusion_matches_the_reference_run():
+    """right_num / total_num and the skipped names as the reference script printed them: four weights, names missing from
+    either score file (or both), exact two- and three-way ties of the fused score (numpy.argmax: first maximum)."""
+    import os
+    G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'ensemble.npz'))
+    names = [str(n) for n in G['names']]
+    labels, sa, sb = G['labels'], G['score_a'], G['score_b']
+    ma, mb = set(G['missing_a'].tolist()), set(G['missing_b'].tolist())
+    ra = {n: sa[i] for i, n in enumerate(names) if i not in ma}
+    rb = {n: sb[i] for i, n in enumerate(names) if i not in mb}
+    for alpha in (float(a) for a in G['alphas']):
+        got = E.ensemble_by_name([ra, rb], [1.0, alpha], names, labels, softmax=False)
+        assert [got['correct'], got['total']] == G[f'alpha{alpha}/right_total'].tolist()
+        assert f"{got['acc']:.4f}" == f"{float(G[f'alpha{alpha}/acc4']):.4f}"
+        assert got['skipped'] == [str(x) for x in G[f'alpha{alpha}/skipped']]
+        assert got['pred'] == EO.fuse_raw(ra, rb, alpha, names, labels)[3]
 
 
 def test_raw_fusion_by_name_matches_the_script_loop():

@@ -143,6 +143,40 @@ def test_refolds_after_every_kind_of_state_change(golden_models):
     assert float((a3 - a2).abs().max()) > 1e-3 * float(a2.abs().max())
 
 
+def test_refolds_after_a_flat_arena_step(golden_models):
+    """with a ParamArena the optimiser writes the flat buffer (no p._version bump); an eval batch of <= 32 clips
+    after such a step must use the NEW weights: f2 == the general eval path, and both differ from before the step."""
+    from tam_gcn_amd.distributed import ParamArena, SGDNesterov
+    m, _ = _model('ucla_t52', gold=golden_models)
+    m = m.to(DEV).eval()
+    arena = ParamArena(m)
+    bucket = arena.grad_bucket()
+    opt = SGDNesterov(arena.params, lr=0.05, momentum=0.9, weight_decay=1e-4, arena=arena, bucket=bucket)
+    x = make_input((2, 3, 52, 20, 1), seed=MODEL_X_SEED).to(DEV)
+
+    def pair():
+        import os
+        with torch.no_grad():
+            a = m(x)
+            os.environ['TAMGCN_F2'] = '0'
+            try:
+                b = m(x)
+            finally:
+                os.environ['TAMGCN_F2'] = '1'
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
+        return a
+    a0 = pair()
+    g = torch.Generator().manual_seed(3)
+    for _ in range(2):                                     # eval mode throughout: no train-mode BatchNorm forward in between
+        for p in arena.params:
+            p.grad = (torch.randn(p.shape, generator=g) * p.detach().abs().mean().cpu()).to(DEV)
+        bucket.pack()
+        opt.step()
+        a1 = pair()
+        assert float((a1 - a0).abs().max()) > 1e-3 * float(a0.abs().max())
+        a0 = a1
+
+
 def test_graph_replay_and_launch_count():
     """inference.GraphedForward captures this path: replay = eager bit for bit; 53 ABI launches per forward (5 per block,
     stem, pool + fc) against 118 of the general eval path."""
