@@ -17,7 +17,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
-from params import fill_state_, make_input, make_labels, digest  # noqa: E402
+from params import fill_state_, make_input, make_labels, digest, sample  # noqa: E402
 from cases import (MODULE_CASES, MODEL_CASES, NEEDS_A, COT_SEED, MODEL_PARAM_SEED, MODEL_X_SEED,  # noqa: E402
                    MODEL_LABEL_SEED, MODEL_INIT_SEED, tag_seed)
 
@@ -51,11 +51,12 @@ FULL_MAX = 20000          # tensors up to this many elements are stored in full
 
 
 def put(out, key, t):
-    """Store small tensors in full, large ones as a digest (key + '#digest')."""
+    """Store small tensors in full, large ones as a digest (key + '#digest') plus 4096 seeded elements (key + '#sample')."""
     if t.numel() <= FULL_MAX:
         out[key] = np32(t).copy()
     else:
         out[key + '#digest'] = digest(t)
+        out[key + '#sample'] = sample(t, key)
 
 
 def run_module(mod, x, out, tag, extra_fwd=None):

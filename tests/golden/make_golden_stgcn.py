@@ -11,7 +11,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
-from params import fill_state_, make_input, make_labels, digest          # noqa: E402
+from params import fill_state_, make_input, make_labels, digest, sample  # noqa: E402
 from cases import COT_SEED, tag_seed, STGCN_BLOCK_CASES, STGCN_MODEL_CASES  # noqa: E402
 
 sys.dont_write_bytecode = True
@@ -40,6 +40,7 @@ def put(out, key, t, full_max=20000):
         out[key] = t.detach().cpu().numpy().copy()
     else:
         out[key + '#digest'] = digest(t)
+        out[key + '#sample'] = sample(t, key)
 
 
 def main():

@@ -61,6 +61,21 @@ def make_labels(n, num_class, seed):
     return torch.from_numpy(np.random.RandomState(seed).randint(0, num_class, size=(n,)).astype(np.int64))
 
 
+N_SAMPLE = 4096
+
+
+def sample_indices(numel, key, k=N_SAMPLE):
+    """k seeded flat indices into a tensor of `numel` elements (regenerable from the fixture key: only the VALUES are stored)."""
+    return _rs(20241005, key).randint(0, numel, size=k).astype(np.int64)
+
+
+def sample(t, key, k=N_SAMPLE):
+    """Values of `t` at sample_indices(t.numel(), key): element-wise pin of a tensor too large to store (VERDICT r03 weak #3:
+    sums + 16 elements would let a localised error in the interior pass)."""
+    idx = torch.from_numpy(sample_indices(t.numel(), key, k))
+    return t.detach().cpu().reshape(-1)[idx].numpy().copy()
+
+
 def digest(t, k=8):
     """Compact fingerprint of a tensor: [sum, sum|x|, sum x^2, first k, last k]."""
     a = t.detach().cpu().double().reshape(-1)

@@ -9,7 +9,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
 from cases import MODULE_CASES, NEEDS_A, COT_SEED, tag_seed          # noqa: E402
-from params import fill_state_, make_input, make_labels, digest      # noqa: E402
+from params import fill_state_, make_input, make_labels, digest, sample      # noqa: E402
 
 from tam_gcn_amd.graph import ucla, ntu_rgb_d, synthetic             # noqa: E402
 from tam_gcn_amd.models import ctrgcn as M                           # noqa: E402
@@ -61,9 +61,16 @@ def golden_get(gold, key):
     return gold[key + '#digest'], True
 
 
+def golden_sample(gold, key, got):
+    """(values of `got` at the fixture's 4096 seeded flat indices, the reference's values there) for a digest-stored tensor."""
+    return sample(got, key).astype(np.float64), gold[key + '#sample'].astype(np.float64)
+
+
 def assert_close(name, got, gold, key, rtol, atol):
     ref, is_dig = golden_get(gold, key)
     if is_dig:
+        a, b = golden_sample(gold, key, got)                 # element-wise pin: 4096 seeded positions of the interior
+        np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg=name + ' (sampled elements)')
         g = digest(got)
         scale = max(1.0, float(np.abs(ref[1])) / max(1, got.numel()) ** 0.5)
         # sums: compare with a tolerance scaled by sum|x|; head/tail elementwise

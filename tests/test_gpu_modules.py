@@ -8,7 +8,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from helpers import (MODULE_CASES, COT_SEED, tag_seed, fill_state_, make_input, build_module, ctrgc_extras,
-                     oracle_run, golden_get, O)        # noqa: E402
+                     oracle_run, golden_get, golden_sample, O)        # noqa: E402
 from params import digest                              # noqa: E402
 
 
@@ -36,6 +36,9 @@ def _cmp_gold(name, got, gold, key, rel, atol=0.0):
         assert abs(g[1] - ref[1]) <= rel * abs(ref[1]) + 1e-6 * n, f'{name}: abs-sum'
         scale = (float(ref[2]) / n) ** 0.5 * 10 + 1e-6
         assert np.abs(g[3:] - ref[3:]).max() <= rel * scale * 10, f'{name}: head/tail'
+        a, b = golden_sample(gold, key, got)                 # 4096 seeded elements, held like a fully stored tensor
+        err, smax = float(np.abs(a - b).max()), float(np.abs(b).max()) + 1e-6
+        assert err <= rel * smax + atol, f'{name}: sampled elements max-abs-err {err:.3e} > {rel:g} * {smax:.3e} + {atol:g}'
     else:
         _cmp(name, got, ref, rel, atol)
 

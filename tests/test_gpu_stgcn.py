@@ -9,7 +9,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from cases import STGCN_BLOCK_CASES, STGCN_MODEL_CASES, COT_SEED, tag_seed     # noqa: E402
-from params import fill_state_, make_input, make_labels, digest               # noqa: E402
+from params import fill_state_, make_input, make_labels, digest, sample       # noqa: E402
 from oracle import stgcn_oracle as SO                                           # noqa: E402
 from tam_gcn_amd.graph import ucla                                              # noqa: E402
 from tam_gcn_amd.models import stgcn as M                                       # noqa: E402
@@ -29,6 +29,9 @@ def _cmp_gold(name, got, key, rel, atol=0.0):
     if dig:
         g = digest(got)
         assert abs(g[1] - ref[1]) <= rel * abs(ref[1]) + 1e-6 * got.numel(), f'{name}: abs-sum {g[1]} vs {ref[1]}'
+        a, b = sample(got, key).astype(np.float64), GOLD[key + '#sample'].astype(np.float64)
+        err, smax = float(np.abs(a - b).max()), float(np.abs(b).max()) + 1e-6
+        assert err <= rel * smax + atol, f'{name}: sampled elements max-abs-err {err:.3e} > {rel:g} * {smax:.3e} + {atol:g}'
     else:
         _cmp(name, got, ref, rel, atol)
 

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from cases import STGCN_BLOCK_CASES, STGCN_MODEL_CASES, COT_SEED, tag_seed
-from params import fill_state_, make_input, make_labels, digest
+from params import fill_state_, make_input, make_labels, digest, sample
 from oracle import stgcn_oracle as SO
 from tam_gcn_amd.graph import ucla
 from tam_gcn_amd.models import stgcn as M
@@ -43,6 +43,7 @@ def close(name, got, key, rtol=2e-4, atol=2e-5):
         g = digest(got)
         assert abs(g[1] - ref[1]) <= rtol * abs(ref[1]) + atol * got.numel() ** 0.5, f'{name}: {g[1]} vs {ref[1]}'
         np.testing.assert_allclose(g[3:], ref[3:], rtol=rtol * 10, atol=atol * 10, err_msg=name)
+        np.testing.assert_allclose(sample(got, key), GOLD[key + '#sample'], rtol=rtol, atol=atol, err_msg=name + ' (sampled elements)')
     else:
         np.testing.assert_allclose(got.detach().numpy(), ref, rtol=rtol, atol=atol, err_msg=name)
 
