@@ -290,6 +290,38 @@ int tamgcn_gcn_mid_bwd(const float* dsum, const float* ddiff, const float* y_pre
                        const float* r_pre, const float* r_save,
                        int N, int C, int T, int V, float* dyb, float* dres, float* part, void* stream);
 
+/* ------------------------------------------------------------------------
+ * The second stage of MultiScale_TemporalConv in one launch per direction (reference models/ctrgcn.py:52-69, 101-119,
+ * 137-147; backward: aten::convolution_backward's input gradient of every branch's k x 1 convolution).
+ *   forward   for b < nb:  y[:, ycoff + b*Cb + m, t] = bias_b[m] + sum_{k, tap} W_b[m][k][tap] *
+ *                              act(src)[:, src.coff + b*Cb + k, t*stride + tap*dil_b - (KT-1)*dil_b/2]      (zero padded)
+ *             pool = 1:    y[:, ycoff + nb*Cb + c, t] = max_{i in -1..1} act(src)[:, src.coff + nb*Cb + c, t*stride + i]
+ *             stats_part (optional) [2][stats_ctot][nparts]: (sum y, sum y^2) per workgroup at the channels of y.
+ *             The prologue must be BatchNorm + ReLU (src.act = 1, no second source).
+ *   backward  src = the gradient w.r.t. y, (N, src.ctot, T_out, V), linear two-source prologue (act = 0);
+ *             for b < nb:  y[:, ycoff + b*Cb + k, th] = [mask value > 0] * sum_{m, tap, t: t*stride + tap*dil_b - pad_b = th}
+ *                              W_b[m][k][tap] * src value[:, src.coff + b*Cb + m, t],        y has T_in frames;
+ *             mask = the forward's source with its prologue (channel mask.coff + b*Cb + k); stats_part: (sum y,
+ *             sum y * (mask.x1 - center[channel])), the entry BatchNorm's backward moments.  pool is ignored (the pooled
+ *             branch's gradient is tamgcn_maxpool_bwd).
+ * Built for Cb = 16 or a multiple of 32, KT in {3, 5}, (KT-1)*dil even, V <= 32 or V % 16 == 0: tamgcn_tconv_supported()
+ * says whether a shape is; w_b = [Cb][Cb][KT] as nn.Conv2d stores it. */
+#define TAMGCN_TCONV_MAXB 6
+typedef struct tamgcn_tconv_desc {
+    tamgcn_src src;
+    int N, T_in, T_out, V, Cb, nb, KT, stride, pool;     /* T_in: frames of the forward's input, T_out = (T_in-1)/stride + 1 */
+    int dil[TAMGCN_TCONV_MAXB];
+    const float* w[TAMGCN_TCONV_MAXB];
+    const float* bias[TAMGCN_TCONV_MAXB];                /* forward only; entries may be NULL */
+    float* y; int yctot, ycoff;
+    float* stats_part; int stats_ctot;
+    const tamgcn_src* mask; const float* center;         /* backward only */
+} tamgcn_tconv_desc;
+int tamgcn_tconv_supported(int V, int Cb, int KT, int nb, const int* dil, int stride, int T_in);
+int tamgcn_tconv_nparts(const tamgcn_tconv_desc* d, int backward);
+int tamgcn_tconv_fwd(const tamgcn_tconv_desc* d, void* stream);
+int tamgcn_tconv_bwd(const tamgcn_tconv_desc* d, void* stream);
+
 /* MaxPool2d((3,1), stride (s,1), pad (1,0)) over the prologue value (models/ctrgcn.py:117),
  * written at channel ycoff of y (N, yctot, T_out, V) + (sum, sum^2) partials [2][yctot][nparts]. */
 int tamgcn_maxpool_fwd(const tamgcn_src* src, int N, int C, int T_in, int V, int stride,

@@ -32,6 +32,19 @@ class ConvDesc(C.Structure):
                 ('post_coef', C.c_void_p), ('post_ctot', C.c_int), ('post_act', C.c_int)]
 
 
+TCONV_MAXB = 6
+
+
+class TconvDesc(C.Structure):
+    _fields_ = [('src', Src),
+                ('N', C.c_int), ('T_in', C.c_int), ('T_out', C.c_int), ('V', C.c_int), ('Cb', C.c_int), ('nb', C.c_int),
+                ('KT', C.c_int), ('stride', C.c_int), ('pool', C.c_int),
+                ('dil', C.c_int * TCONV_MAXB), ('w', C.c_void_p * TCONV_MAXB), ('bias', C.c_void_p * TCONV_MAXB),
+                ('y', C.c_void_p), ('yctot', C.c_int), ('ycoff', C.c_int),
+                ('stats_part', C.c_void_p), ('stats_ctot', C.c_int),
+                ('mask', C.POINTER(Src)), ('center', C.c_void_p)]
+
+
 class WgradDesc(C.Structure):
     _fields_ = [('gy', Src), ('src', Src),
                 ('N', C.c_int), ('M', C.c_int), ('K', C.c_int), ('T_in', C.c_int), ('T_out', C.c_int),
@@ -126,6 +139,10 @@ SIGNATURES = {
     'tamgcn_gcn_tail_fwd': (_i, [_SP, _SP, _SP, _i, _i, _i, _i, _p, _p]),
     'tamgcn_gcn_tail_bwd': (_i, [_p, _p, _SP, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
     'tamgcn_gcn_mid_bwd': (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
+    'tamgcn_tconv_supported': (_i, [_i, _i, _i, _i, C.POINTER(C.c_int), _i, _i]),
+    'tamgcn_tconv_nparts': (_i, [C.POINTER(TconvDesc), _i]),
+    'tamgcn_tconv_fwd': (_i, [C.POINTER(TconvDesc), _p]),
+    'tamgcn_tconv_bwd': (_i, [C.POINTER(TconvDesc), _p]),
     'tamgcn_maxpool_fwd': (_i, [_SP, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _p]),
     'tamgcn_maxpool_post_fwd': (_i, [_SP, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _p, _i, _p]),
     'tamgcn_maxpool_bwd': (_i, [_SP, _SP, _p, _i, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p]),

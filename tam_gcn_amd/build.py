@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = ['lib.hip', 'conv.hip', 'bn.hip', 'elementwise.hip', 'ctrgc.hip', 'ctrgc_de.hip', 'ctrgc_tiled.hip', 'stemhead.hip', 'feeder.hip', 'f2.hip']
+SRC = ['lib.hip', 'conv.hip', 'bn.hip', 'elementwise.hip', 'ctrgc.hip', 'ctrgc_de.hip', 'ctrgc_tiled.hip', 'stemhead.hip', 'feeder.hip', 'f2.hip', 'tconv.hip']
 LIB = os.path.join(HERE, 'libtamgcn.so')
 ARCH = 'gfx950'
 

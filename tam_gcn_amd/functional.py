@@ -452,16 +452,23 @@ def tcn_forward(g, P, training, save, xres=None, pool=None):
         P.bn_in[b].fwd(hpart, b * Cb, cnt1, training, coef_h, save_h, b * Cb, batch=bi)
     bi.flush()
     fk.refork()                                        # h_pre and coef_h are ready on main
-    for b in range(nb):
-        k, d = P.ks[b], P.dils[b]
-        with (fk.on(b) if b > 0 else contextlib.nullcontext()):        # branch 0 on main, the others beside it
-            _, part = ops.conv(S(h_pre, coef=coef_h, coff=b * Cb, act=RELU), K=Cb, w=P.Wt[b], bias=P.bt[b], M=Cb,
-                               KT=k, dil=d, stride=s, pad=_tpad(k, d), y=cat_pre, ycoff=b * Cb, T_out=T2,
-                               stats=training)
+    if ops.tconv_supported(V, Cb, P.ks, P.dils, s, T):
+        # every temporal branch and the pooled one in ONE launch (csrc/tconv.hip): h_pre is read once per branch slice
+        part = ops.tconv_fwd(S(h_pre, coef=coef_h, act=RELU), Cb, P.ks[0], P.dils, s, P.Wt, P.bt, True, cat_pre, 0, stats=training)
+        for b in range(nb):
             P.bn_t[b].fwd(part, b * Cb, cnt2, training, coef_c, save_c, b * Cb, batch=bo)
-    with fk.on(0):
-        part = ops.maxpool_fwd(S(h_pre, coef=coef_h, coff=nb * Cb, act=RELU), Cb, s, cat_pre, nb * Cb, stats=training)
         P.bn_pool.fwd(part, nb * Cb, cnt2, training, coef_c, save_c, nb * Cb, batch=bo)
+    else:
+        for b in range(nb):
+            k, d = P.ks[b], P.dils[b]
+            with (fk.on(b) if b > 0 else contextlib.nullcontext()):        # branch 0 on main, the others beside it
+                _, part = ops.conv(S(h_pre, coef=coef_h, coff=b * Cb, act=RELU), K=Cb, w=P.Wt[b], bias=P.bt[b], M=Cb,
+                                   KT=k, dil=d, stride=s, pad=_tpad(k, d), y=cat_pre, ycoff=b * Cb, T_out=T2,
+                                   stats=training)
+                P.bn_t[b].fwd(part, b * Cb, cnt2, training, coef_c, save_c, b * Cb, batch=bo)
+        with fk.on(0):
+            part = ops.maxpool_fwd(S(h_pre, coef=coef_h, coff=nb * Cb, act=RELU), Cb, s, cat_pre, nb * Cb, stats=training)
+            P.bn_pool.fwd(part, nb * Cb, cnt2, training, coef_c, save_c, nb * Cb, batch=bo)
     r_pre = coef_r = save_r = None
     if xres is None:
         xres = g
@@ -586,16 +593,22 @@ def _tcn_backward(P, sv, dout, need_dg=True, need_dxres=True):
     # every branch's weight gradient follows on a side stream
     marks = []
     bi = ops.BNBatch()                                 # the entry norms' backward: one launch once every dh slice is written
+    fused = ops.tconv_supported(V, Cb, P.ks, P.dils, s, T)
+    if fused:                                          # every temporal branch's data gradient in ONE launch (csrc/tconv.hip)
+        hp_all = ops.tconv_bwd(gcat(0), Cb, P.ks[0], P.dils, s, P.Wt, S(h_pre, coef=sv['coef_h']), sv['save_h'], dh, 0)
     for b in range(nb):
         k, d = P.ks[b], P.dils[b]
         pad = _tpad(k, d)
-        with (fk.on(b) if b > 0 else contextlib.nullcontext()):
-            _, hp = ops.conv(gcat(b * Cb), K=Cb, w=P.Wt[b], bias=None, M=Cb, KT=k, dil=d, stride=1,
-                             pad=(k - 1) * d - pad, wmode=1, up=s, y=dh, ycoff=b * Cb, T_out=T,
-                             mask=S(h_pre, coef=sv['coef_h'], coff=b * Cb), aux=h_pre, aux_center=sv['save_h'], auxcoff=b * Cb,
-                             stats=True)
+        if fused:
+            hp = hp_all
+        else:
+            with (fk.on(b) if b > 0 else contextlib.nullcontext()):
+                _, hp = ops.conv(gcat(b * Cb), K=Cb, w=P.Wt[b], bias=None, M=Cb, KT=k, dil=d, stride=1,
+                                 pad=(k - 1) * d - pad, wmode=1, up=s, y=dh, ycoff=b * Cb, T_out=T,
+                                 mask=S(h_pre, coef=sv['coef_h'], coff=b * Cb), aux=h_pre, aux_center=sv['save_h'], auxcoff=b * Cb,
+                                 stats=True)
         dgam, dbet, dbias = P.bn_in[b].bwd(hp, b * Cb, cnt1, sv['save_h'], b * Cb, training, coefb_h, b * Cb, True, batch=bi)
-        if b > 0:
+        if b > 0 and not fused:
             marks.append(fk.mark(b))                   # dh slice and moments of branch b done (its wgrad is not awaited)
         G['bn_in'].append((dgam, dbet))
         dbin.append(dbias)

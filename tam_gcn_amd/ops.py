@@ -8,7 +8,7 @@ import threading
 import torch
 
 from . import _lib
-from ._lib import Src, ConvDesc, WgradDesc, CtrgcDesc, ReduceDesc
+from ._lib import Src, ConvDesc, WgradDesc, CtrgcDesc, ReduceDesc, TconvDesc, TCONV_MAXB
 
 RELU = 1
 
@@ -153,6 +153,74 @@ def conv(src, K, w, bias, M, KT=1, dil=1, stride=1, pad=0, wmode=0, up=1,
         d.stats_part, d.stats_ctot, d.stats_coff = _ptr(part), y.shape[1], ycoff
     _lib.check(lib.tamgcn_conv(C.byref(d), _stream()), 'tamgcn_conv')
     return y, part
+
+
+# ---------------------------------------------------------------------------
+# the MS-TCN second stage in one launch per direction (csrc/tconv.hip)
+TCONV = os.environ.get('TAMGCN_TCONV', '1') != '0'         # 0: every branch through tamgcn_conv / tamgcn_maxpool_fwd (A/B, tests)
+
+
+def tconv_supported(V, Cb, ks, dils, stride, T_in):
+    """True when tamgcn_tconv_fwd / _bwd are built for this branch geometry (one kernel size for every branch)."""
+    if not TCONV or not dils or len(dils) > TCONV_MAXB or any(k != ks[0] for k in ks):
+        return False
+    arr = (C.c_int * len(dils))(*[int(d_) for d_ in dils])
+    return bool(_lib_().tamgcn_tconv_supported(V, Cb, int(ks[0]), len(dils), arr, stride, T_in))
+
+
+def _tconv_desc(src, Cb, KT, dils, stride, ws, T_in, T_out, y, ycoff):
+    d = TconvDesc()
+    d.src = src.c()
+    d.N, d.T_in, d.T_out, d.V, d.Cb, d.nb, d.KT, d.stride = src.x1.shape[0], T_in, T_out, src.x1.shape[3], Cb, len(dils), KT, stride
+    for b, (dl, w) in enumerate(zip(dils, ws)):
+        if tuple(w.shape[:3]) != (Cb, Cb, KT):
+            raise RuntimeError(f'tamgcn_tconv: branch {b} weight {tuple(w.shape)}, expected ({Cb}, {Cb}, {KT}, 1)')
+        d.dil[b], d.w[b] = int(dl), _ptr(w)
+    d.y, d.yctot, d.ycoff = _ptr(y), y.shape[1], ycoff
+    return d
+
+
+def tconv_fwd(src, Cb, KT, dils, stride, ws, biases, pool, y, ycoff=0, stats=False):
+    """Every temporal branch (and the pooled one) of an MS-TCN block: y[:, ycoff + b*Cb ...] for b < len(dils) (+ 1 with pool).
+    src: S over (N, ctot, T_in, V) with the BatchNorm + ReLU prologue; returns the moment partials [2][yctot][nparts] or None."""
+    N, _, T_in, V = src.x1.shape
+    T_out = y.shape[2]
+    if src.x1.shape[-1] % 4:
+        src = S(with_slack(src.x1), None, src.coef, src.coff, src.act)
+    d = _tconv_desc(src, Cb, KT, dils, stride, ws, T_in, T_out, y, ycoff)
+    d.pool = int(bool(pool))
+    for b, bi in enumerate(biases):
+        d.bias[b] = _ptr(bi)
+    lib = _lib_()
+    part = None
+    if stats:
+        nparts = lib.tamgcn_tconv_nparts(C.byref(d), 0)
+        if nparts <= 0:
+            raise RuntimeError('tamgcn_tconv_fwd: no tiling for this shape')
+        part = empty(2, y.shape[1], nparts, like=y)
+        d.stats_part, d.stats_ctot = _ptr(part), y.shape[1]
+    _lib.check(lib.tamgcn_tconv_fwd(C.byref(d), _stream()), 'tamgcn_tconv_fwd')
+    return part
+
+
+def tconv_bwd(gy, Cb, KT, dils, stride, ws, mask, center, dh, dcoff=0):
+    """Data gradient of the temporal branches into dh[:, dcoff + b*Cb ...] (N, dctot, T_in, V), masked by relu(mask) > 0;
+    returns the entry BatchNorm's backward moment partials [2][dctot][nparts]."""
+    T_in, T_out = dh.shape[2], gy.x1.shape[2]
+    if gy.x1.shape[-1] % 4:
+        gy = S(with_slack(gy.x1), with_slack(gy.x2), gy.coef, gy.coff, gy.act)
+        mask = S(with_slack(mask.x1), None, mask.coef, mask.coff, mask.act)
+    d = _tconv_desc(gy, Cb, KT, dils, stride, ws, T_in, T_out, dh, dcoff)
+    mc = mask.c()
+    d.mask, d.center = C.pointer(mc), _ptr(center)
+    lib = _lib_()
+    nparts = lib.tamgcn_tconv_nparts(C.byref(d), 1)
+    if nparts <= 0:
+        raise RuntimeError('tamgcn_tconv_bwd: no tiling for this shape')
+    part = empty(2, dh.shape[1], nparts, like=dh)
+    d.stats_part, d.stats_ctot = _ptr(part), dh.shape[1]
+    _lib.check(lib.tamgcn_tconv_bwd(C.byref(d), _stream()), 'tamgcn_tconv_bwd')
+    return part
 
 
 WGRAD_BLOCKS = int(os.environ.get('TAMGCN_WGRAD_BLOCKS', '512'))    # workgroups a weight gradient aims at (tiles x splits)

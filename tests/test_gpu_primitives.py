@@ -466,3 +466,86 @@ def test_kx1_weight_gradient_taps_with_prologue(shape, monkeypatch):
             assert err <= bar, (mode, err)
     finally:
         lib.tamgcn_set_split_mode(prev)
+
+
+# N, Cb, T, V, KT, dilations, stride  (the MS-TCN second stage: temporal branches + pooled branch in one launch)
+TCONV_CASES = [
+    (2, 16, 64, 20, 5, (1, 2), 1),        # l1-l4
+    (3, 16, 13, 20, 5, (1, 2), 1),        # ragged T: one partial frame tile
+    (2, 32, 33, 20, 5, (1, 2), 2),        # l5: strided, odd T
+    (2, 32, 32, 20, 5, (1, 2), 1),
+    (2, 64, 32, 20, 5, (1, 2), 2),        # l8: two 32-row output halves, strided
+    (2, 64, 16, 20, 5, (1, 2), 1),
+    (2, 16, 20, 20, 3, (1, 2, 3, 4), 1),  # MultiScale_TemporalConv's constructor defaults
+    (2, 32, 14, 25, 5, (1, 2), 1),        # NTU: rows of 25 joints (Vp = 28, dword-aligned 16-byte accesses)
+    (2, 32, 15, 25, 5, (1, 2), 2),
+    (1, 64, 40, 64, 5, (1, 2), 1),        # V = 64: four joint slices
+    (1, 16, 9, 64, 3, (2,), 2),
+]
+
+
+@pytest.mark.parametrize('case', TCONV_CASES, ids=lambda c: 'x'.join(str(x).replace(' ', '') for x in c))
+def test_tconv_fused_branches_fwd_bwd(case):
+    """tamgcn_tconv_fwd / _bwd (csrc/tconv.hip) against fp64 torch: conv2d per branch + max_pool2d on relu(bn(h)) slices
+    of a wider tensor, written into slices of a wider output; the BatchNorm moment partials; the data gradient with the
+    ReLU mask and the entry BatchNorm's backward moments."""
+    from tam_gcn_amd import ops
+    from tam_gcn_amd.ops import S
+    N, Cb, T, V, KT, dils, s = case
+    nb = len(dils)
+    d = dev()
+    assert ops.tconv_supported(V, Cb, [KT] * nb, list(dils), s, T)
+    T2 = (T - 1) // s + 1
+    lead, tail = 16, 8                                  # channels in front of / behind the branch slices
+    Ch = lead + (nb + 1) * Cb + tail
+    Co = 8 + (nb + 1) * Cb + 8
+    h1 = rnd((N, Ch, T, V), 1)
+    ch = torch.stack((1 + 0.3 * rnd((Ch,), 2), torch.zeros(Ch), 0.2 * rnd((Ch,), 3)))
+    ws = [rnd((Cb, Cb, KT, 1), 10 + b) * (1.0 / (Cb * KT)) ** 0.5 for b in range(nb)]
+    bs = [0.1 * rnd((Cb,), 20 + b) for b in range(nb)]
+    hv = torch.relu(ch[0].double()[None, :, None, None] * h1.double() + ch[2].double()[None, :, None, None])
+    hv.requires_grad_(True)
+    outs = []
+    for b in range(nb):
+        pad = (KT - 1) * dils[b] // 2
+        outs.append(F.conv2d(hv[:, lead + b * Cb: lead + (b + 1) * Cb], ws[b].double(), bs[b].double(), stride=(s, 1),
+                             padding=(pad, 0), dilation=(dils[b], 1)))
+    outs.append(F.max_pool2d(hv[:, lead + nb * Cb: lead + (nb + 1) * Cb], kernel_size=(3, 1), stride=(s, 1), padding=(1, 0)))
+    ref = torch.cat(outs, 1)
+    assert ref.shape[2] == T2
+    t = lambda z: z.to(d)
+    y = torch.full((N, Co, T2, V), 7.0, device=d)
+    part = ops.tconv_fwd(S(t(h1), None, t(ch), coff=lead, act=1), Cb, KT, list(dils), s, [t(w) for w in ws], [t(b_) for b_ in bs],
+                         True, y, 8, stats=True)
+    torch.cuda.synchronize()
+    got = y[:, 8:8 + (nb + 1) * Cb].double().cpu()
+    scale = float(ref.abs().max())
+    assert float((got - ref.detach()).abs().max()) <= 2e-6 * scale
+    assert float((y[:, :8] - 7).abs().max()) == 0 and float((y[:, 8 + (nb + 1) * Cb:] - 7).abs().max()) == 0    # neighbours untouched
+    sums = part.double().sum(2).cpu()[:, 8:8 + (nb + 1) * Cb]
+    cnt = N * T2 * V
+    assert float((sums[0] - ref.detach().sum((0, 2, 3))).abs().max()) <= 2e-6 * scale * cnt
+    assert float((sums[1] - (ref.detach() ** 2).sum((0, 2, 3))).abs().max()) <= 4e-6 * scale * scale * cnt
+    # ---- data gradient of the temporal branches: gy = c1*g1 + c2*g2 + c0 on slices of wider tensors
+    Cg = 4 + nb * Cb + 4
+    g1, g2 = rnd((N, Cg, T2, V), 30), rnd((N, Cg, T2, V), 31)
+    cg = torch.stack((1 + 0.2 * rnd((Cg,), 32), 0.3 * rnd((Cg,), 33), 0.1 * rnd((Cg,), 34)))
+    gv = (cg[0].double()[None, :, None, None] * g1.double() + cg[1].double()[None, :, None, None] * g2.double() +
+          cg[2].double()[None, :, None, None])[:, 4:4 + nb * Cb]
+    (ref[:, :nb * Cb] * gv).sum().backward()
+    # d relu(bn(h)) -> d (bn(h)) by the mask; the product's contract stops there (the BatchNorm backward is the consumer's prologue)
+    dref = (hv.grad * (hv.detach() > 0))[:, lead: lead + nb * Cb]
+    mu = 0.1 * rnd((Ch,), 40)
+    dh = torch.full((N, Ch, T, V), 3.0, device=d)
+    bpart = ops.tconv_bwd(S(t(g1), t(g2), t(cg), coff=4), Cb, KT, list(dils), s, [t(w) for w in ws],
+                          S(t(h1), None, t(ch), coff=lead), t(mu), dh, lead)
+    torch.cuda.synchronize()
+    gotd = dh[:, lead: lead + nb * Cb].double().cpu()
+    dscale = float(dref.abs().max())
+    assert float((gotd - dref).abs().max()) <= 2e-6 * dscale
+    assert float((dh[:, :lead] - 3).abs().max()) == 0 and float((dh[:, lead + nb * Cb:] - 3).abs().max()) == 0
+    bs_ = bpart.double().sum(2).cpu()[:, lead: lead + nb * Cb]
+    cnt1 = N * T * V
+    hc = (h1.double() - mu.double()[None, :, None, None])[:, lead: lead + nb * Cb]
+    assert float((bs_[0] - dref.sum((0, 2, 3))).abs().max()) <= 2e-6 * dscale * cnt1
+    assert float((bs_[1] - (dref * hc).sum((0, 2, 3))).abs().max()) <= 4e-6 * dscale * float(hc.abs().max()) * cnt1
