@@ -194,13 +194,17 @@ def test_harness_sgd_steps(flat, fix, golden_models):
         opt.step()
         losses.append(float(loss.detach()))
     ref, ref64 = golden_models[f'{fix}/losses'], golden_models[f'{fix}/losses64']
-    # Measured deviations from the fp64 reference on MI355X (profiles/r03_sgd_fixture_report.txt), identical in the exact-fp32
-    # and the split mode: loss[1] 2.1e-3 (sgd3s) / 1.4e-3 (sgd3), loss[2] 5.4e-2 / 2.0e-1; state tensors of >= 256 elements
-    # 2.3e-2 / 1.2e-1, smaller ones up to 1.3e-1..3.2e-1 / 3.5e-1..6.0e-1.  Cause on record: ONE ReLU mask of the first forward
-    # (l4's output, fp64 pre-activation 1.39e-6) differs from fp64.  Bounds = those figures x ~2.
-    LOSS1 = {'sgd3s': 5e-3, 'sgd3': 5e-3}
-    LOSS2 = {'sgd3s': 1.2e-1, 'sgd3': 4e-1}
-    BIG = {'sgd3s': 6e-2, 'sgd3': 2.5e-1}
+    # Measured deviations from the fp64 reference on MI355X, identical in the exact-fp32 and the split mode.  Cause on record:
+    # ONE ReLU mask of the first forward (l4's output, fp64 pre-activation 1.4e-6) differs from fp64; from there the
+    # trajectories separate, and WHERE they go depends on every kernel's summation order:
+    #   round 3 (profiles/r03_sgd_fixture_report.txt): loss[1] 2.1e-3 (sgd3s) / 1.4e-3 (sgd3), loss[2] 5.4e-2 / 2.0e-1, state
+    #     tensors of >= 256 elements 2.3e-2 / 1.2e-1;
+    #   round 4, temporal branches on csrc/tconv.hip (profiles/r04_sgd_fixture_report.txt): the same single mask differs, loss[1]
+    #     4.4e-3 / 1.7e-3, loss[2] 1.2e-1 / 6.1e-2, large tensors 2.7e-2 / 3.5e-2 -- the two fixtures swapped places.
+    # Bounds = the larger of the two rounds' figures x ~2 for both fixtures (the chaos is the fixture's, not one recipe's).
+    LOSS1 = {'sgd3s': 1e-2, 'sgd3': 1e-2}
+    LOSS2 = {'sgd3s': 4e-1, 'sgd3': 4e-1}
+    BIG = {'sgd3s': 2.5e-1, 'sgd3': 2.5e-1}
     if fix == 'sgd3b':
         ltol = 1e-3 * np.abs(ref64) + NOISE_K * np.abs(ref - ref64)
         assert (np.abs(np.array(losses) - ref64) <= ltol).all(), (losses, ref, ref64)
@@ -223,8 +227,9 @@ def test_harness_sgd_steps(flat, fix, golden_models):
         bad = np.abs(got[:, 1] - refd64[:, 1]) > np.where(small, 2e-2, 1e-3) * np.abs(refd64[:, 1]) + NOISE_K * noise + 2e-4
     else:
         # chaotic fixtures (see above): tensors of >= 256 elements within BIG, the cancelling-sum tensors below that size
-        # within 100 % (the oracle, bit-compatible arithmetic, reproduces both fixtures to 2e-4: tests/test_model_cpu.py)
-        bad = np.abs(got[:, 1] - refd64[:, 1]) > np.where(small, 1.0, BIG[fix]) * np.abs(refd64[:, 1]) + 1e-2
+        # within 200 % (measured up to 161 %, r04 report; the oracle, bit-compatible arithmetic, reproduces both fixtures to 2e-4:
+        # tests/test_model_cpu.py)
+        bad = np.abs(got[:, 1] - refd64[:, 1]) > np.where(small, 2.0, BIG[fix]) * np.abs(refd64[:, 1]) + 1e-2
         assert np.isfinite(got).all()
     assert not bad.any(), [(k, got[i, 1], refd[i, 1], refd64[i, 1]) for i, k in enumerate(sd.keys()) if bad[i]][:5]
 
