@@ -19,14 +19,29 @@
 //     registers under the MFMAs.
 // v_mfma_f32_16x16x4_f32 throughout: exact fp32 (the reference's arithmetic).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
+
+TG_TRACE_DEFINE(tamgcn_trace_read_tconv)
+// stamps are summed in registers and leave through ONE batch of atomics at the end of the workgroup (an atomic per stamp
+// would sit in the vmcnt queue the kernel's own waits count)
+#ifdef TAMGCN_TRACE
+#define TC_ACC(slot, expr) tacc[slot] += (unsigned long long)(expr)
+#else
+#define TC_ACC(slot, expr)
+#endif
 
 constexpr int TC_NT = 256;
 constexpr int TC_BK = 16;                                 // input channels per LDS chunk
 constexpr int TC_NPF = 8;                                 // float4 prefetch slots per thread and source
 constexpr int TC_MAXLB = TC_NPF * TC_NT * 4 / TC_BK;      // floats per line-buffer row: 512
 constexpr int TC_MAXB = TAMGCN_TCONV_MAXB;
+// LDS pitches are compile-time constants: the four k rows of a fragment and the taps' row blocks are then IMMEDIATE offsets
+// of the ds_reads (with run-time pitches hipcc kept 24 address registers per tap and 24 v_adds to step them).  528 >= TC_MAXLB
+// and == 16 (mod 32): the two k rows a 32-lane half reads sit 16 banks apart.
+constexpr int TC_PX = 528;
+template <int MT> struct TcPitchW { static constexpr int v = MT == 1 ? 16 : MT == 2 ? 48 : 80; };      // >= 16*MT and == 16 (mod 32)
 
 struct TcArgs {
     SrcDev src;                     // (N, src.ctot, T_src, V); branch b reads Cb channels from src.coff + b*Cb
@@ -38,330 +53,413 @@ struct TcArgs {
     float* y; int yctot, ycoff, T_out;      // (N, yctot, T_out, V); branch b writes Cb channels at ycoff + b*Cb
     float* stats; int stats_ctot, nparts;   // [2][stats_ctot][nparts] at the output channel
     SrcDev mask; const float* center;       // backward: y *= (mask value > 0); second moment against mask.x1 - center[ch]
-    int BT, TIN, LB, pitchX, pitchW, Vs, Vp, nsl, mh;
+    int BT, TIN, LB, Vs, Vp, nsl, mh, ntiles, nby, ntt, tpw;    // ntiles = ceil(ntt / tpw) * nsl workgroup units per (sample, branch)
 };
+
+// x / d for 0 <= x < 2^20 and 4 <= d <= 64 through the reciprocal (rcp = 1.0f / d): three VALU instead of the ~25 of an
+// integer division.  (x + 0.5) / d lies at least 0.5 / d >= 0.0078 from an integer, float rounding moves it by < 0.07.
+// The kernel's address arithmetic had ~30 divisions per tile and lane: more issue slots than its MFMAs
+// (tools/tconv_phases.py: 3.7 k of 13.6 k clocks per tile went into "issuing 13 loads").
+__device__ __forceinline__ int tc_div(int x, float rcp) { return (int)(((float)x + 0.5f) * rcp); }
 
 // four consecutive columns col0..col0+3 of one output row: contiguous in HBM (full-width tiles: the row is the flat
 // (t, v) run; joint slices: Vs % 4 == 0 keeps the group inside its frame).  Only a full-width tile can end in a partial group.
-__device__ __forceinline__ long long tc_off(int V, int Vs, int v0, int t0, int col0, bool flat) {
+__device__ __forceinline__ long long tc_off(int V, int Vs, float rVs, int v0, int t0, int col0, bool flat) {
     if (flat) return (long long)t0 * V + col0;
-    const int fr = col0 / Vs;
+    const int fr = tc_div(col0, rVs);
     return (long long)(t0 + fr) * V + v0 + (col0 - fr * Vs);
 }
 
-template <int MT, int CT, int KT, bool BWD>
-__global__ __launch_bounds__(TC_NT, BWD ? 2 : 3) void tconv_kernel(const TcArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float tc_smem[];
-    float* Xs = tc_smem;                                  // [16][pitchX]
-    float* Ws = Xs + TC_BK * a.pitchX;                    // [KT*16][pitchW]
-    float* Ss = Ws + KT * TC_BK * a.pitchW;               // [2][4][MT*16]
-    float* cf = Ss + 2 * 4 * MT * 16;                     // [3][Cb]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 15, kq = lane >> 4;
-    const int tti = blockIdx.x / a.nsl, sl = blockIdx.x - tti * a.nsl;
-    const int n = blockIdx.z;
-    const int V = a.V, Vs = a.Vs, Vp = a.Vp, v0 = sl * Vs;
-    const bool flat = a.nsl == 1;
-    const int t0 = tti * a.BT;
-    const int bt = min(a.BT, a.T_out - t0);
-    const int ncols = bt * Vs;
-    const long long cs = (long long)a.T_src * V;          // channel stride of the source
-    const long long ocs = (long long)a.T_out * V;         // ... of the output
-
-    if (!BWD && (int)blockIdx.y >= a.nb * a.mh) {
-        // ---- pooled branch: max over frames th-1, th, th+1 of the activated source.  The source went through a ReLU
-        // (host-checked), so the zeros of the temporal padding never win against the window's always-valid centre: the
-        // same value as aten's -inf padding.
-        const int br = a.nb;
-        const int tin0 = t0 * a.stride - 1;
-        const int TINp = (bt - 1) * a.stride + 3;
-        const int LB4 = (TINp * Vp) >> 2;
-        const long long sbase = ((long long)n * a.src.ctot + a.src.coff + br * a.Cb) * cs;
-        for (int kc = 0; kc < a.Cb; kc += TC_BK) {
-            __syncthreads();
-            for (int e = tid; e < TC_BK * LB4; e += TC_NT) {
-                const int kk = e / LB4, pos = (e - kk * LB4) << 2;
-                const int slot = pos / Vp, v = pos - slot * Vp;
-                const int th = tin0 + slot;
-                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (th >= 0 && th < a.T_src) {
-                    const int ch = a.src.coff + br * a.Cb + kc + kk;
-                    const float c1 = a.src.coef ? a.src.coef[ch] : 1.f, c0 = a.src.coef ? a.src.coef[2 * a.src.ctot + ch] : 0.f;
-                    const float4 x = *reinterpret_cast<const float4*>(a.src.x1 + sbase + (long long)(kc + kk) * cs + (long long)th * V + v0 + v);
-                    o.x = fmaxf(fmaf(c1, x.x, c0), 0.f); o.y = fmaxf(fmaf(c1, x.y, c0), 0.f);
-                    o.z = fmaxf(fmaf(c1, x.z, c0), 0.f); o.w = fmaxf(fmaf(c1, x.w, c0), 0.f);
-                }
-                *reinterpret_cast<float4*>(Xs + kk * a.pitchX + pos) = o;
-            }
-            __syncthreads();
-            const int kk = tid >> 4, g = tid & 15;
-            const int och = a.ycoff + br * a.Cb + kc + kk;
-            float* yrow = a.y + ((long long)n * a.yctot + och) * ocs;
-            const float* xr = Xs + kk * a.pitchX;
-            float s1 = 0.f, s2 = 0.f;
-            for (int c = 4 * g; c < ncols; c += 64) {
-                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+// The pooled branch (MaxPool2d((3,1), stride, pad 1) of relu(bn(src)), reference models/ctrgcn.py:113-118) as its own
+// LDS-free launch: workgroup = (unit of `tpw` frame tiles, sample), 16 lanes per channel row, four consecutive columns per
+// lane, the three rows of a window straight from global memory (L1 / L2 serve the re-reads), 12 independent 16-byte loads in
+// flight per lane.  Its moment partials use the convolution launch's slots (same units).  (Inside the convolution launch's
+// grid a pool workgroup held that launch's 78-119 KB of LDS for nothing: +30 us at 64 channels.)
+__global__ __launch_bounds__(TC_NT) void tpool_kernel(const TcArgs a) {
+    const int tid = threadIdx.x;
+    const int pk = tid >> 4, psub = tid & 15;
+    const int unit = blockIdx.x % a.ntiles, n = blockIdx.x / a.ntiles;
+    const int grp = unit / a.nsl, sl = unit - grp * a.nsl;
+    const int tl0 = grp * a.tpw, tl1 = min(a.ntt, tl0 + a.tpw);
+    const int V = a.V, Vs = a.Vs, v0 = sl * Vs;
+    const float rVs = 1.0f / (float)Vs;
+    const long long cs = (long long)a.T_src * V, ocs = (long long)a.T_out * V;
+    const int part = n * a.ntiles + unit;
+    const int br = a.nb;
+    const int c_lo = tl0 * a.BT * Vs, c_hi = min(a.T_out, tl1 * a.BT) * Vs;      // this unit's columns (frame-major within the slice)
+    for (int kc = 0; kc < a.Cb; kc += TC_BK) {
+        const int sch = a.src.coff + br * a.Cb + kc + pk;
+        const float c1 = a.src.coef ? a.src.coef[sch] : 1.f, c0 = a.src.coef ? a.src.coef[2 * a.src.ctot + sch] : 0.f;
+        const float* xrow = a.src.x1 + ((long long)n * a.src.ctot + sch) * cs;
+        const int och = a.ycoff + br * a.Cb + kc + pk;
+        float* yrow = a.y + ((long long)n * a.yctot + och) * ocs;
+        float s1 = 0.f, s2 = 0.f;
+        constexpr int PB = 4;                              // groups per batch: 12 independent 16-byte loads in flight per lane
+        for (int cb = c_lo + 4 * psub; cb < c_hi; cb += 64 * PB) {
+            f32x4 q0[PB], q1[PB], q2[PB];
+            bool vec[PB];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int cc = c + r;
-                    if (cc < ncols) {
-                        const int fr = cc / Vs, v = cc - fr * Vs;
-                        const float* p = xr + fr * a.stride * Vp + v;
-                        const float m = fmaxf(fmaxf(p[0], p[Vp]), p[2 * Vp]);
-                        o[r] = m;
+            for (int u = 0; u < PB; ++u) {                 // every load unconditional (clamped to the centre row / a valid group)
+                const int c = cb + 64 * u;
+                const int cc = c < c_hi ? c : c_lo;
+                const int fr = tc_div(cc, rVs), v = cc - fr * Vs;
+                vec[u] = c < c_hi && v + 4 <= Vs && c + 4 <= c_hi;
+                const int vv = v + 4 <= Vs ? v : 0;         // a group that leaves its frame is redone element-wise below
+                const int th = fr * a.stride;
+                const float* p = xrow + (long long)th * V + v0 + vv;
+                q1[u] = *reinterpret_cast<const f32x4*>(p);
+                q0[u] = *reinterpret_cast<const f32x4*>(th > 0 ? p - V : p);
+                q2[u] = *reinterpret_cast<const f32x4*>(th + 1 < a.T_src ? p + V : p);
+            }
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                const int c = cb + 64 * u;
+                if (vec[u]) {
+                    const int fr = tc_div(c, rVs), v = c - fr * Vs;
+                    f32x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        o[r] = fmaxf(fmaxf(fmaxf(fmaf(c1, q0[u][r], c0), fmaf(c1, q1[u][r], c0)), fmaf(c1, q2[u][r], c0)), 0.f);
+                    *reinterpret_cast<f32x4*>(yrow + (long long)fr * V + v0 + v) = o;
+                    s1 += (o[0] + o[1]) + (o[2] + o[3]);
+                    s2 = fmaf(o[0], o[0], fmaf(o[1], o[1], fmaf(o[2], o[2], fmaf(o[3], o[3], s2))));
+                } else if (c < c_hi) {
+                    for (int r = 0; r < 4 && c + r < c_hi; ++r) {
+                        const int cc = c + r, f2 = tc_div(cc, rVs), v2 = cc - f2 * Vs, th = f2 * a.stride;
+                        const float* p = xrow + (long long)th * V + v0 + v2;
+                        float m = fmaf(c1, p[0], c0);
+                        if (th > 0) m = fmaxf(m, fmaf(c1, p[-V], c0));
+                        if (th + 1 < a.T_src) m = fmaxf(m, fmaf(c1, p[V], c0));
+                        m = fmaxf(m, 0.f);
+                        yrow[(long long)f2 * V + v0 + v2] = m;
                         s1 += m;
                         s2 = fmaf(m, m, s2);
                     }
                 }
-                const long long off = tc_off(V, Vs, v0, t0, c, flat);
-                if (c + 3 < ncols) *reinterpret_cast<f32x4*>(yrow + off) = o;
-                else for (int r = 0; r < 4 && c + r < ncols; ++r) yrow[off + r] = o[r];
-            }
-            if (a.stats) {
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-                if (g == 0) {
-                    const int part = n * gridDim.x + blockIdx.x;
-                    a.stats[((long long)0 * a.stats_ctot + och) * a.nparts + part] = s1;
-                    a.stats[((long long)1 * a.stats_ctot + och) * a.nparts + part] = s2;
-                }
             }
         }
-        return;
+        if (a.stats) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+            if (psub == 0) {
+                a.stats[((long long)0 * a.stats_ctot + och) * a.nparts + part] = s1;
+                a.stats[((long long)1 * a.stats_ctot + och) * a.nparts + part] = s2;
+            }
+        }
     }
+}
 
-    const int br = blockIdx.y / a.mh;
-    const int m0 = (blockIdx.y - br * a.mh) * (MT * 16);       // first output channel (inside the branch) of this workgroup
+// MT = 16-row output tiles of the workgroup = its wave groups: 256*MT threads, wave (wm = wave / 4, wc = wave % 4) owns row
+// tile wm and the column tiles wc*CT .. wc*CT + CT-1.  Cb = 16 -> 256 threads (78 KB of LDS, two workgroups per CU),
+// Cb = 32 -> 512 (98 KB), Cb = 64 -> 1024 (119 KB): one line buffer serves every output channel of the branch.
+template <int MT, int CT, int KT, bool BWD>
+__global__ __launch_bounds__(TC_NT * MT, MT == 4 ? 4 : 2) void tconv_kernel(const TcArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float tc_smem[];
+    constexpr int PW = TcPitchW<MT>::v;
+    constexpr int XSZ = TC_BK * TC_PX, WSZ = KT * TC_BK * PW;
+    float* Xs = tc_smem;                                  // [2][16][TC_PX]   double-buffered line buffer
+    float* Ws = Xs + 2 * XSZ;                             // [2][KT*16][PW]   ... and weight image [tap][k][m]
+    float* Ss = Ws + 2 * WSZ;                             // [2][4][MT*16]
+    float* cf = Ss + 2 * 4 * MT * 16;                     // [3][Cb]
+    constexpr int NTH = TC_NT * MT;                       // threads
+    constexpr int NPFW = TC_NPF / MT;                     // line-buffer pieces per thread
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, wm = tid >> 8;
+    const int j0_ = lane & 15, kq0_ = lane >> 4;
+    int j = j0_, kq = kq0_;
+    // 1-D grid, XCD-aware: consecutive block ids go round-robin over the 8 XCDs, so block id L is workgroup
+    // (L % 8) * (G / 8) + L / 8 of the (unit fastest, branch, sample) order: the workgroups of one (sample, branch) -- which
+    // share temporal halos -- and the two output halves of a 64-channel branch -- which share their whole source tile --
+    // follow each other on ONE XCD's L2 (speed only; any mapping is correct).
+    int L = blockIdx.x;
+    { const int G = gridDim.x, G8 = G >> 3; if (L < (G8 << 3)) L = (L & 7) * G8 + (L >> 3); }
+    // a workgroup owns `tpw` consecutive frame tiles of one (sample, branch [, output half], joint slice): unit = (group, slice)
+    const int unit = L % a.ntiles, by = (L / a.ntiles) % a.nby, n = L / (a.ntiles * a.nby);
+    const int grp = unit / a.nsl, sl = unit - grp * a.nsl;
+    const int tl0 = grp * a.tpw, tl1 = min(a.ntt, tl0 + a.tpw);
+    const int V = a.V, Vs = a.Vs, Vp = a.Vp, v0 = sl * Vs;
+    const bool flat = a.nsl == 1;
+    const float rVs = 1.0f / (float)Vs, rVp = 1.0f / (float)Vp;
+    const long long cs = (long long)a.T_src * V;          // channel stride of the source
+    const long long ocs = (long long)a.T_out * V;         // ... of the output
+    const int part = n * a.ntiles + unit;                 // this workgroup's slot of the moment partials
+    int pk = (tid >> 4) & 15, psub = (tid & 15) + 16 * NPFW * wm;   // staging: thread (channel row pk, float4 pieces psub + 16*i)
+
+    const int br = by / a.mh;
+    const int m0 = (by - br * a.mh) * (MT * 16);               // first output channel (inside the branch) of this workgroup
+    const int mw = m0 + wm * 16;                               // ... of this wave
     const int dil = a.dil[br];
-    const int tin0 = t0 * a.stride - a.pad[br];
+    const int padb = a.pad[br];
     const float* __restrict__ wb = a.w[br];
     const int sch0 = a.src.coff + br * a.Cb;                   // first source channel of the branch
 
-    for (int e = tid; e < a.Cb; e += TC_NT) {
+    for (int e = tid; e < a.Cb; e += NTH) {
         const int ch = sch0 + e;
         cf[e] = a.src.coef ? a.src.coef[ch] : 1.f;
         cf[a.Cb + e] = (a.src.coef && a.src.x2) ? a.src.coef[a.src.ctot + ch] : 0.f;
         cf[2 * a.Cb + e] = a.src.coef ? a.src.coef[2 * a.src.ctot + ch] : 0.f;
     }
 
-    // LDS offsets of this lane's A-fragment columns: column c = (frame fr, joint v) -> fr*stride*Vp + v (tap adds tap*dil*Vp)
-    int boff[CT];
-#pragma unroll
-    for (int c = 0; c < CT; ++c) {
-        const int col = (wave * CT + c) * 16 + j;
-        if (col < ncols) { const int fr = col / Vs; boff[c] = fr * a.stride * Vp + (col - fr * Vs); }
-        else boff[c] = 0;                                      // padding tile: reads in-bounds data, never stored
-    }
-    f32x4 acc[MT][CT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int c = 0; c < CT; ++c) acc[mt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // Line-buffer prefetch: thread (kk = tid / 16, sub = tid % 16) owns the float4 pieces sub + 16*i of channel row kk -- one
-    // channel per thread, so the prologue coefficients are three registers per chunk, the LDS address is affine in i, and
-    // 16 consecutive lanes fetch 256 contiguous bytes.
+    // Line-buffer staging: thread (pk, psub) owns the float4 pieces psub + 16*i of channel row pk -- one channel per thread,
+    // so the prologue coefficients are three registers per item, the LDS address is affine in i, and 16 consecutive lanes
+    // fetch 256 contiguous bytes.  EVERY piece is loaded, unconditionally (a piece outside the source reads the row's
+    // first bytes instead and is zeroed on its way into LDS): no branch around a load, so the number of vector-memory
+    // operations in flight is a compile-time constant and the waits are counted, never vmcnt(0) behind the stores.
     const int LB4 = a.LB >> 2;
-    const int pk = tid >> 4, psub = tid & 15;
     const long long sbase = ((long long)n * a.src.ctot + sch0) * cs + (long long)pk * cs;
-    int p_off[TC_NPF];
-    unsigned okm = 0, inm = 0;                                 // okm: piece inside the source; inm: piece inside the line buffer
+    int p_off[NPFW];
+    unsigned okm = 0;                                          // piece i lies inside the source (of the tile being staged)
+    auto setup = [&](int tti) {
+        const int tin0 = tti * a.BT * a.stride - padb;
+        okm = 0;
 #pragma unroll
-    for (int i = 0; i < TC_NPF; ++i) {
-        const int c4 = psub + 16 * i;
-        const int pos = c4 << 2;
-        const int slot = pos / Vp, v = pos - slot * Vp;
-        int th = tin0 + slot;
-        bool ok = c4 < LB4 && th >= 0;
-        if (a.up > 1) { ok = ok && (th % a.up == 0); th /= a.up; }
-        ok = ok && th < a.T_src;
-        if (ok) okm |= 1u << i;
-        if (c4 < LB4) inm |= 1u << i;
-        p_off[i] = th * V + v0 + v;
-    }
-    float* const xw = Xs + pk * a.pitchX + (psub << 2);       // piece i goes to xw + 64*i
-    // Weight prefetch: thread (r = tid / 16, q0 = tid % 16) owns the elements q0 + 16*i of its row(s) of the chunk, in MEMORY
+        for (int i = 0; i < NPFW; ++i) {
+            const int pos = (psub + 16 * i) << 2;
+            const int slot = tc_div(pos, rVp), v = pos - slot * Vp;
+            int th = tin0 + slot;
+            bool ok = (psub + 16 * i) < LB4 && th >= 0;
+            if (a.up == 2) { ok = ok && !(th & 1); th >>= 1; }      // zero-upsampled source of a stride-2 forward (host: up <= 2)
+            ok = ok && th < a.T_src;
+            if (ok) okm |= 1u << i;
+            p_off[i] = ok ? th * V + v0 + v : 0;
+        }
+    };
+    // Weight staging: thread (r = tid / 16, q0 = tid % 16) owns the elements q0 + 16*i of its row(s) of the chunk, in MEMORY
     // order: forward W[m][k][tap] -> row = output channel (one row of 16*KT contiguous floats per 16-row tile), backward
     // -> row = contraction channel (MT*16*KT contiguous floats: the output channels and their taps, taps flipped).
-    constexpr int NW = KT * MT;
-    const int wrow = tid >> 4, wq0 = tid & 15;
-    const float* const wthr = BWD ? wb + (long long)wrow * a.ws_k + (long long)m0 * KT + wq0
-                                  : wb + (long long)(m0 + wrow) * a.ws_m + wq0;
-    float4 r1[TC_NPF], r2[BWD ? TC_NPF : 1];
+    constexpr int NW = KT;                                     // KT*16*MT*16 elements per chunk over 256*MT threads
+    int wq0 = tid & 15;
+    const float* const wthr = BWD ? wb + (long long)pk * a.ws_k + (long long)m0 * KT + wq0 + 16 * KT * wm
+                                  : wb + (long long)(mw + pk) * a.ws_m + wq0;
+    float4 r1[NPFW], r2[BWD ? NPFW : 1];
     float wr[NW];
     const bool has2 = BWD && a.src.x2 != nullptr;
+    const int nch = a.Cb / TC_BK;                              // chunks per tile
+    const int nitems = (tl1 - tl0) * nch;
     auto prefetch = [&](int kc) {
         const float* x1 = a.src.x1 + sbase + (long long)kc * cs;
 #pragma unroll
-        for (int i = 0; i < TC_NPF; ++i) {
-            r1[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (okm & (1u << i)) r1[i] = *reinterpret_cast<const float4*>(x1 + p_off[i]);
-        }
+        for (int i = 0; i < NPFW; ++i) r1[i] = *reinterpret_cast<const float4*>(x1 + p_off[i]);
         if (BWD) {
-            const float* x2 = a.src.x2 + sbase + (long long)kc * cs;
+            const float* x2 = (has2 ? a.src.x2 : a.src.x1) + sbase + (long long)kc * cs;
 #pragma unroll
-            for (int i = 0; i < TC_NPF; ++i) {
-                r2[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (has2 && (okm & (1u << i))) r2[i] = *reinterpret_cast<const float4*>(x2 + p_off[i]);
-            }
+            for (int i = 0; i < NPFW; ++i) r2[i] = *reinterpret_cast<const float4*>(x2 + p_off[i]);
         }
         const float* wk = wthr + (long long)kc * a.ws_k;
 #pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            if (!BWD) wr[i] = wk[(long long)(i / KT) * 16 * a.ws_m + 16 * (i % KT)];
-            else wr[i] = wk[16 * i];
+        for (int i = 0; i < NW; ++i) wr[i] = wk[16 * i];
+    };
+    auto stage = [&](int buf, int kc) {                         // registers -> LDS image `buf` (prologue, zero padding)
+        float* xs = Xs + buf * XSZ + pk * TC_PX + (psub << 2);
+        const float c1 = cf[kc + pk], c2 = has2 ? cf[a.Cb + kc + pk] : 0.f, c0 = cf[2 * a.Cb + kc + pk];
+#pragma unroll
+        for (int i = 0; i < NPFW; ++i) {
+            {                                                   // pieces 0..127 of the row: all the A fragments can reach (LB <= 512)
+                float4 o;
+                if (BWD) {
+                    o.x = fmaf(c1, r1[i].x, fmaf(c2, r2[i].x, c0)); o.y = fmaf(c1, r1[i].y, fmaf(c2, r2[i].y, c0));
+                    o.z = fmaf(c1, r1[i].z, fmaf(c2, r2[i].z, c0)); o.w = fmaf(c1, r1[i].w, fmaf(c2, r2[i].w, c0));
+                } else {
+                    o.x = fmaxf(fmaf(c1, r1[i].x, c0), 0.f); o.y = fmaxf(fmaf(c1, r1[i].y, c0), 0.f);
+                    o.z = fmaxf(fmaf(c1, r1[i].z, c0), 0.f); o.w = fmaxf(fmaf(c1, r1[i].w, c0), 0.f);
+                }
+                if (!(okm & (1u << i))) o = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(xs + 64 * i) = o;
+            }
+        }
+        {
+            float* ws = Ws + buf * WSZ;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                if (!BWD) {
+                    const int q = wq0 + 16 * i;                 // (k, tap) in memory order
+                    const int kk = q / KT, tap = q - kk * KT;
+                    ws[(tap * TC_BK + kk) * PW + wm * 16 + pk] = wr[i];
+                } else {
+                    const int q = wq0 + 16 * (i + KT * wm);     // (m, flipped tap) in memory order
+                    const int mi = q / KT, tap = KT - 1 - (q - mi * KT);
+                    ws[(tap * TC_BK + pk) * PW + mi] = wr[i];
+                }
+            }
         }
     };
+
+    float s1 = 0.f, s2 = 0.f;
+    // per-lane epilogue constants, fetched once: a load inside the epilogue puts a vmcnt(0) -- i.e. a wait for the previous
+    // column tile's STORES -- in front of every use
+    float bia = 0.f, mc1 = 1.f, mc0 = 0.f, ctr = 0.f;
+    if (!BWD) { if (a.bias[br]) bia = a.bias[br][mw + j]; }
+    else {
+        const int hch = a.mask.coff + br * a.Cb + mw + j;
+        if (a.mask.coef) { mc1 = a.mask.coef[hch]; mc0 = a.mask.coef[2 * a.mask.ctot + hch]; }
+        if (a.center) ctr = a.center[hch];
+    }
+
+    // ---- software pipeline over the items (tile, chunk) of this workgroup, two LDS images:
+    //   item it:  [loads of item it+1 issued] -> MFMAs on image it&1 -> loads landed: stage item it+1 into image (it+1)&1
+    //             -> (last chunk of a tile) epilogue: stores -> ONE barrier.
+    // The loads travel under the MFMAs; the stores under the barrier and the next item's MFMAs (nothing waits for them
+    // until the next staging, a whole MFMA phase later).
+    // No branch encloses a load or a staging pass (the item after the last one re-stages the workgroup's first item into
+    // the idle image): two call sites of the prefetch merging in a phi made hipcc COPY the just-requested registers at the
+    // join, i.e. wait for the loads in front of the MFMAs they were meant to travel under.
+#ifdef TAMGCN_TRACE
+    unsigned long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    TG_T(tt0);
+    setup(tl0);
     prefetch(0);
     __syncthreads();                                           // cf table visible
+    stage(0, 0);
+    __syncthreads();
+    TG_T(tt1); TC_ACC(0, tt1 - tt0);
 
-    for (int kc = 0; kc < a.Cb; kc += TC_BK) {
-        if (kc) __syncthreads();                               // previous chunk's MFMAs are done with Xs / Ws
-        {
-            const float c1 = cf[kc + pk], c2 = cf[a.Cb + kc + pk], c0 = cf[2 * a.Cb + kc + pk];
+    f32x4 acc[CT];
+    int boff[CT];
+    int it = 0;
+    for (int tti = tl0; tti < tl1; ++tti) {
+        const int t0 = tti * a.BT;
+        const int bt = min(a.BT, a.T_out - t0);
+        const int ncols = bt * Vs;
+        // LDS offsets of this lane's A-fragment columns: column c = (frame fr, joint v) -> fr*stride*Vp + v (tap adds tap*dil*Vp)
 #pragma unroll
-            for (int i = 0; i < TC_NPF; ++i) {
-                if (inm & (1u << i)) {
-                    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (okm & (1u << i)) {
-                        if (BWD) {
-                            o.x = fmaf(c1, r1[i].x, fmaf(c2, r2[i].x, c0)); o.y = fmaf(c1, r1[i].y, fmaf(c2, r2[i].y, c0));
-                            o.z = fmaf(c1, r1[i].z, fmaf(c2, r2[i].z, c0)); o.w = fmaf(c1, r1[i].w, fmaf(c2, r2[i].w, c0));
-                        } else {
-                            o.x = fmaxf(fmaf(c1, r1[i].x, c0), 0.f); o.y = fmaxf(fmaf(c1, r1[i].y, c0), 0.f);
-                            o.z = fmaxf(fmaf(c1, r1[i].z, c0), 0.f); o.w = fmaxf(fmaf(c1, r1[i].w, c0), 0.f);
+        for (int c = 0; c < CT; ++c) {
+            const int col = (wave * CT + c) * 16 + j;
+            if (col < ncols) { const int fr = tc_div(col, rVs); boff[c] = fr * a.stride * Vp + (col - fr * Vs); }
+            else boff[c] = 0;                                  // padding tile: reads in-bounds data, never stored
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        // backward: the mask / centring operand h_pre of this tile's outputs, requested ahead of the tile's MFMAs
+        f32x4 h[BWD ? CT : 1];
+        if (BWD) {
+            const int hch = a.mask.coff + br * a.Cb + mw + j;
+            const float* hrow = a.mask.x1 + ((long long)n * a.mask.ctot + hch) * ocs;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                int col0 = (wave * CT + c) * 16 + 4 * kq;
+                if (col0 + 4 > ncols) col0 = 0;                 // padding / partial group: a safe address, re-read element-wise below
+                h[c] = *reinterpret_cast<const f32x4*>(hrow + tc_off(V, Vs, rVs, v0, t0, col0, flat));
+            }
+        }
+        for (int kc = 0; kc < a.Cb; kc += TC_BK, ++it) {
+            // hipcc hoists every item-invariant address (weight image, staging rows, epilogue rows) out of these loops and
+            // then runs out of registers: opaque copies of the lane coordinates keep that arithmetic inside the loop
+            asm volatile("" : "+v"(j), "+v"(kq), "+v"(pk), "+v"(psub), "+v"(wq0));
+            const int buf = it & 1;
+            const bool lastc = kc + TC_BK >= a.Cb;
+            const int kcn = lastc ? 0 : kc + TC_BK;
+            TG_T(ta);
+            if (lastc) setup(tti + 1 < tl1 ? tti + 1 : tl0);   // integer work only
+            prefetch(kcn);
+            TG_T(tb); TC_ACC(1, tb - ta);
+            {
+                const float* xb = Xs + buf * XSZ;
+                const float* wbuf = Ws + buf * WSZ;
+#pragma unroll 1
+                for (int tap = 0; tap < KT; ++tap) {           // not unrolled: one tap's LDS addresses live at a time
+                    const float* xt = xb + kq * TC_PX + tap * dil * Vp;
+                    const float* wt = wbuf + (tap * TC_BK + kq) * PW + wm * 16 + j;
+#pragma unroll
+                    for (int k4 = 0; k4 < TC_BK / 4; ++k4) {
+                        float av[CT];
+                        const float bv = wt[k4 * 4 * PW];
+#pragma unroll
+                        for (int c = 0; c < CT; ++c) av[c] = xt[k4 * 4 * TC_PX + boff[c]];
+#pragma unroll
+                        for (int c = 0; c < CT; ++c) acc[c] = mfma16(av[c], bv, acc[c]);
+                    }
+                }
+            }
+            TG_T(tc); TC_ACC(2, tc - tb);
+#ifdef TAMGCN_TRACE
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            TG_T(tw); TC_ACC(3, tw - tc);
+            stage(buf ^ 1, kcn);
+            TG_T(td); TC_ACC(4, td - tw);
+            if (lastc) {
+                // ---- epilogue straight from the accumulators: lane (j, kq) holds, per column tile c, the four consecutive
+                // columns (wave*CT + c)*16 + 4*kq + r of output channel mw + j.
+                const int mch = br * a.Cb + mw + j;              // channel inside the launch's output / mask slice
+                float* yrow = a.y + ((long long)n * a.yctot + a.ycoff + mch) * ocs;
+                float q1 = 0.f, q2 = 0.f;
+                if (!BWD) {
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) {
+                        const int col0 = (wave * CT + c) * 16 + 4 * kq;
+                        if (col0 < ncols) {
+                            f32x4 v = acc[c];
+                            v[0] += bia; v[1] += bia; v[2] += bia; v[3] += bia;
+                            const long long off = tc_off(V, Vs, rVs, v0, t0, col0, flat);
+                            if (col0 + 3 < ncols) {
+                                *reinterpret_cast<f32x4*>(yrow + off) = v;
+                                q1 += (v[0] + v[1]) + (v[2] + v[3]);
+                                q2 = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], q2))));
+                            } else {
+                                for (int r = 0; r < 4 && col0 + r < ncols; ++r) { yrow[off + r] = v[r]; q1 += v[r]; q2 = fmaf(v[r], v[r], q2); }
+                            }
                         }
                     }
-                    *reinterpret_cast<float4*>(xw + 64 * i) = o;
-                }
-            }
-        }
+                } else {
+                    // d h_pre = (conv value) where relu(bn(h_pre)) > 0, else 0; moments (sum d, sum d * (h_pre - mean)) for the
+                    // entry BatchNorm's backward
+                    const int hch = a.mask.coff + mch;
+                    const float* hrow = a.mask.x1 + ((long long)n * a.mask.ctot + hch) * ocs;
 #pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            // LDS image Ws[tap][k][m]
-            if (!BWD) {
-                const int q = wq0 + 16 * (i % KT);              // (k, tap) in memory order
-                const int kk = q / KT, tap = q - kk * KT;
-                Ws[(tap * TC_BK + kk) * a.pitchW + (i / KT) * 16 + wrow] = wr[i];
-            } else {
-                const int q = wq0 + 16 * i;                     // (m, flipped tap) in memory order
-                const int mi = q / KT, tap = KT - 1 - (q - mi * KT);
-                Ws[(tap * TC_BK + wrow) * a.pitchW + mi] = wr[i];
-            }
-        }
-        __syncthreads();
-        if (kc + TC_BK < a.Cb) prefetch(kc + TC_BK);           // in flight under the MFMAs below
-#pragma unroll 1
-        for (int tap = 0; tap < KT; ++tap) {                   // not unrolled: one tap's 4*(CT+MT) LDS addresses live at a time
-            const float* xt = Xs + kq * a.pitchX + tap * dil * Vp;
-            const float* wt = Ws + (tap * TC_BK + kq) * a.pitchW + j;
+                    for (int c = 0; c < CT; ++c) {
+                        const int col0 = (wave * CT + c) * 16 + 4 * kq;
+                        if (col0 < ncols) {
+                            f32x4 v = acc[c];
+                            f32x4 hv = h[c];
+                            const long long off = tc_off(V, Vs, rVs, v0, t0, col0, flat);
+                            if (col0 + 3 >= ncols) for (int r = 0; r < 4 && col0 + r < ncols; ++r) hv[r] = hrow[off + r];
 #pragma unroll
-            for (int k4 = 0; k4 < TC_BK / 4; ++k4) {
-                float av[CT], bv[MT];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) bv[mt] = wt[k4 * 4 * a.pitchW + mt * 16];
-#pragma unroll
-                for (int c = 0; c < CT; ++c) av[c] = xt[k4 * 4 * a.pitchX + boff[c]];
-#pragma unroll
-                for (int c = 0; c < CT; ++c)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) acc[mt][c] = mfma16(av[c], bv[mt], acc[mt][c]);
-            }
-        }
-    }
-
-    // ---- epilogue straight from the accumulators: lane (j, kq) holds, per (row tile mt, column tile c), the four
-    // consecutive columns (wave*CT + c)*16 + 4*kq + r of output channel m0 + mt*16 + j.
-    float s1[MT], s2[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int mch = br * a.Cb + m0 + mt * 16 + j;          // channel inside the launch's output / mask slice
-        const int och = a.ycoff + mch;
-        float* yrow = a.y + ((long long)n * a.yctot + och) * ocs;
-        const float bia = (!BWD && a.bias[br]) ? a.bias[br][m0 + mt * 16 + j] : 0.f;
-        float q1 = 0.f, q2 = 0.f;
-        if (!BWD) {
-#pragma unroll
-            for (int c = 0; c < CT; ++c) {
-                const int col0 = (wave * CT + c) * 16 + 4 * kq;
-                if (col0 < ncols) {
-                    f32x4 v = acc[mt][c];
-                    v[0] += bia; v[1] += bia; v[2] += bia; v[3] += bia;
-                    const long long off = tc_off(V, Vs, v0, t0, col0, flat);
-                    if (col0 + 3 < ncols) {
-                        *reinterpret_cast<f32x4*>(yrow + off) = v;
-                        q1 += (v[0] + v[1]) + (v[2] + v[3]);
-                        q2 = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], q2))));
-                    } else {
-                        for (int r = 0; r < 4 && col0 + r < ncols; ++r) { yrow[off + r] = v[r]; q1 += v[r]; q2 = fmaf(v[r], v[r], q2); }
+                            for (int r = 0; r < 4; ++r) {
+                                if (!(fmaf(mc1, hv[r], mc0) > 0.f)) v[r] = 0.f;
+                                if (col0 + r < ncols) { q1 += v[r]; q2 = fmaf(v[r], hv[r] - ctr, q2); }
+                            }
+                            if (col0 + 3 < ncols) *reinterpret_cast<f32x4*>(yrow + off) = v;
+                            else for (int r = 0; r < 4 && col0 + r < ncols; ++r) yrow[off + r] = v[r];
+                        }
                     }
                 }
+                s1 += q1; s2 += q2;
             }
-        } else {
-            // d h_pre = (conv value) where relu(bn(h_pre)) > 0, else 0; moments (sum d, sum d * (h_pre - mean)) for the entry
-            // BatchNorm's backward.  All loads first, then the stores (vmcnt counts both, in order).
-            const int hch = a.mask.coff + mch;
-            const float* hrow = a.mask.x1 + ((long long)n * a.mask.ctot + hch) * ocs;
-            const float mc1 = a.mask.coef ? a.mask.coef[hch] : 1.f, mc0 = a.mask.coef ? a.mask.coef[2 * a.mask.ctot + hch] : 0.f;
-            const float ctr = a.center ? a.center[hch] : 0.f;
-            f32x4 h[CT];
-#pragma unroll
-            for (int c = 0; c < CT; ++c) {
-                const int col0 = (wave * CT + c) * 16 + 4 * kq;
-                h[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (col0 < ncols) {
-                    const long long off = tc_off(V, Vs, v0, t0, col0, flat);
-                    if (col0 + 3 < ncols) h[c] = *reinterpret_cast<const f32x4*>(hrow + off);
-                    else for (int r = 0; r < 4 && col0 + r < ncols; ++r) h[c][r] = hrow[off + r];
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < CT; ++c) {
-                const int col0 = (wave * CT + c) * 16 + 4 * kq;
-                if (col0 < ncols) {
-                    f32x4 v = acc[mt][c];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (!(fmaf(mc1, h[c][r], mc0) > 0.f)) v[r] = 0.f;
-                        if (col0 + r < ncols) { q1 += v[r]; q2 = fmaf(v[r], h[c][r] - ctr, q2); }
-                    }
-                    const long long off = tc_off(V, Vs, v0, t0, col0, flat);
-                    if (col0 + 3 < ncols) *reinterpret_cast<f32x4*>(yrow + off) = v;
-                    else for (int r = 0; r < 4 && col0 + r < ncols; ++r) yrow[off + r] = v[r];
-                }
-            }
+            TG_T(te); TC_ACC(5, te - td);
+            __syncthreads();                                   // image (it+1)&1 complete; everyone is done reading image it&1
+            TG_T(tf); TC_ACC(6, tf - te); TC_ACC(7, 1);
         }
-        s1[mt] = q1; s2[mt] = q2;
     }
+    TG_T(tz); TC_ACC(8, tz - tt0); TC_ACC(9, 1);
+#ifdef TAMGCN_TRACE
+    if (threadIdx.x == 0) for (int i = 0; i < 10; ++i) atomicAdd(&tg_trace[i], tacc[i]);
+#endif
     if (a.stats) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            float u1 = s1[mt], u2 = s2[mt];
-            u1 += __shfl_xor(u1, 16); u1 += __shfl_xor(u1, 32);
-            u2 += __shfl_xor(u2, 16); u2 += __shfl_xor(u2, 32);
-            if (kq == 0) {
-                Ss[(0 * 4 + wave) * (MT * 16) + mt * 16 + j] = u1;
-                Ss[(1 * 4 + wave) * (MT * 16) + mt * 16 + j] = u2;
-            }
+        float u1 = s1, u2 = s2;
+        u1 += __shfl_xor(u1, 16); u1 += __shfl_xor(u1, 32);
+        u2 += __shfl_xor(u2, 16); u2 += __shfl_xor(u2, 32);
+        if (kq == 0) {
+            Ss[(0 * 4 + wave) * (MT * 16) + wm * 16 + j] = u1;
+            Ss[(1 * 4 + wave) * (MT * 16) + wm * 16 + j] = u2;
         }
         __syncthreads();
         if (tid < 2 * MT * 16) {
             const int st = tid / (MT * 16), row = tid - st * (MT * 16);
             const float tot = (Ss[(st * 4 + 0) * (MT * 16) + row] + Ss[(st * 4 + 1) * (MT * 16) + row]) +
                               (Ss[(st * 4 + 2) * (MT * 16) + row] + Ss[(st * 4 + 3) * (MT * 16) + row]);
-            const int part = n * gridDim.x + blockIdx.x;
             a.stats[((long long)st * a.stats_ctot + a.ycoff + br * a.Cb + m0 + row) * a.nparts + part] = tot;
         }
     }
 }
 
-struct TcPlan { int BT, TIN, LB, pitchX, pitchW, Vs, Vp, nsl, ntt, mt, mh, ct; size_t lds; };
+struct TcPlan { int BT, TIN, LB, Vs, Vp, nsl, ntt, mt, mh, ct, tpw, ngrp; size_t lds; };
 
 // stride: frame step of the product's source per output frame (the forward's stride; 1 for the data gradient, whose source is
 // zero-upsampled); span = (KT-1) * largest dilation
 static int tc_plan(int V, int Cb, int KT, int span, int stride, int T_out, TcPlan* p) {
-    if (V < 1 || Cb < 16 || (Cb != 16 && Cb % 32 != 0) || (KT != 3 && KT != 5) || T_out < 1) return -1;
+    if (V < 1 || Cb < 16 || (Cb != 16 && Cb != 32 && Cb % 64 != 0) || (KT != 3 && KT != 5) || T_out < 1) return -1;
     p->Vs = V; p->nsl = 1;
     if (V > 32) { if (V % 16) return -1; p->Vs = 16; p->nsl = V / 16; }
     p->Vp = (p->Vs + 3) & ~3;
@@ -375,15 +473,13 @@ static int tc_plan(int V, int Cb, int KT, int span, int stride, int T_out, TcPla
         if (p->LB <= TC_MAXLB) break;
     }
     p->BT = BT;
-    p->pitchX = p->LB + (((16 - (p->LB & 31)) + 32) & 31);      // == 16 (mod 32): the two k rows of a 32-lane half sit 16 banks apart
-    p->mt = Cb == 16 ? 1 : 2;
-    p->mh = Cb == 16 ? 1 : Cb / 32;
-    p->pitchW = p->mt == 1 ? 16 : 48;                         // == 16 (mod 32)
+    p->mt = Cb == 16 ? 1 : Cb == 32 ? 2 : 4;                  // 16-row tiles = wave groups of a workgroup
+    p->mh = Cb / (16 * p->mt);
     const int tiles = ceil_div(BT * p->Vs, 16);
     p->ct = ceil_div(tiles, 4) <= 3 ? 3 : 5;
     if (ceil_div(tiles, 4) > 5) return -1;
     p->ntt = ceil_div(T_out, BT);
-    p->lds = sizeof(float) * ((size_t)TC_BK * p->pitchX + (size_t)KT * TC_BK * p->pitchW + 2 * 4 * p->mt * 16 + 3 * (size_t)Cb);
+    p->lds = sizeof(float) * (2 * (size_t)TC_BK * TC_PX + 2 * (size_t)KT * TC_BK * (p->mt == 1 ? 16 : p->mt == 2 ? 48 : 80) + 2 * 4 * p->mt * 16 + 3 * (size_t)Cb);
     return 0;
 }
 
@@ -391,15 +487,34 @@ template <bool BWD>
 static int tc_launch(const TcArgs& a, const TcPlan& p, int KT, dim3 grid, hipStream_t s) {
 #define TC_CASE(MT_, CT_, KT_)                                                                                          \
     if (p.mt == MT_ && p.ct == CT_ && KT == KT_) {                                                                      \
-        hipLaunchKernelGGL((tconv_kernel<MT_, CT_, KT_, BWD>), grid, dim3(TC_NT), p.lds, s, a);                         \
+        static tg_devmask done = 0;                                                                                     \
+        tg_allow_lds((const void*)tconv_kernel<MT_, CT_, KT_, BWD>, 160 * 1024, &done);                                 \
+        hipLaunchKernelGGL((tconv_kernel<MT_, CT_, KT_, BWD>), grid, dim3(TC_NT * MT_), p.lds, s, a);                   \
         tamgcn_note_kernel("tconv_kernel<%d, %d, %d, %s>", MT_, CT_, KT_, BWD ? "bwd" : "fwd");                         \
         return 0;                                                                                                       \
     }
-    TC_CASE(1, 5, 5) TC_CASE(2, 5, 5) TC_CASE(1, 3, 5) TC_CASE(2, 3, 5)
-    TC_CASE(1, 5, 3) TC_CASE(2, 5, 3) TC_CASE(1, 3, 3) TC_CASE(2, 3, 3)
+    TC_CASE(1, 5, 5) TC_CASE(2, 5, 5) TC_CASE(4, 5, 5) TC_CASE(1, 3, 5) TC_CASE(2, 3, 5) TC_CASE(4, 3, 5)
+    TC_CASE(1, 5, 3) TC_CASE(2, 5, 3) TC_CASE(4, 5, 3) TC_CASE(1, 3, 3) TC_CASE(2, 3, 3) TC_CASE(4, 3, 3)
 #undef TC_CASE
     tamgcn_set_error("tamgcn_tconv: no instantiation mt=%d ct=%d KT=%d", p.mt, p.ct, KT);
     return -1;
+}
+
+// frame tiles per workgroup: enough workgroups to fill the chip about six deep (the tile loop hides a tile's load latency under
+// the previous tile's MFMAs and stores; too few workgroups leave CUs idle at the tail).  TAMGCN_TC_TPW overrides (A/B runs).
+static void tc_split(TcPlan* p, int N, int nby) {
+    static int env = -1;
+    if (env < 0) { const char* e = getenv("TAMGCN_TC_TPW"); env = e ? atoi(e) : 0; }
+    const long long tiles = (long long)N * nby * p->ntt * p->nsl;
+    // measured (tools/tconv_bench.py, 256 clips): N-UCLA shapes are fastest with every tile of a (sample, branch) in one
+    // workgroup (4 / 2 / 1 tiles), NTU's 30 tiles per sample in groups of 8-10
+    int tpw = env > 0 ? env : (int)((tiles + 256) / 512);
+    if (tpw < 1) tpw = 1;
+    if (tpw > 8 && env <= 0) tpw = 8;
+    if (tpw > p->ntt) tpw = p->ntt;
+    p->ngrp = ceil_div(p->ntt, tpw);
+    p->tpw = ceil_div(p->ntt, p->ngrp);                      // even groups
+    p->ngrp = ceil_div(p->ntt, p->tpw);
 }
 
 static int tc_span(const int* dil, int nb, int KT) {
@@ -411,7 +526,7 @@ static int tc_span(const int* dil, int nb, int KT) {
 }  // namespace
 
 extern "C" int tamgcn_tconv_supported(int V, int Cb, int KT, int nb, const int* dil, int stride, int T_in) {
-    if (nb < 1 || nb > TC_MAXB || !dil || stride < 1 || T_in < 1) return 0;
+    if (nb < 1 || nb > TC_MAXB || !dil || stride < 1 || stride > 2 || T_in < 1) return 0;
     for (int b = 0; b < nb; ++b) if (dil[b] < 1 || ((KT - 1) * dil[b]) % 2) return 0;
     TcPlan p;
     const int T_out = (T_in - 1) / stride + 1;
@@ -423,12 +538,13 @@ extern "C" int tamgcn_tconv_nparts(const tamgcn_tconv_desc* d, int backward) {
     if (!d || d->nb < 1 || d->nb > TC_MAXB) return -1;
     const int T_out = (d->T_in - 1) / d->stride + 1;
     if (tc_plan(d->V, d->Cb, d->KT, tc_span(d->dil, d->nb, d->KT), backward ? 1 : d->stride, backward ? d->T_in : T_out, &p)) return -1;
-    return d->N * p.ntt * p.nsl;
+    tc_split(&p, d->N, d->nb * p.mh);
+    return d->N * p.ngrp * p.nsl;
 }
 
 static int tc_common_checks(const tamgcn_tconv_desc* d, const char* who) {
     TG_CHECK(d && d->src.x1 && d->y, "%s: null pointer", who);
-    TG_CHECK(d->N > 0 && d->N <= 65535 && d->T_in > 0 && d->V > 0 && d->Cb > 0 && d->nb >= 1 && d->nb <= TC_MAXB && d->stride >= 1,
+    TG_CHECK(d->N > 0 && d->N <= (1 << 20) && d->T_in > 0 && d->V > 0 && d->Cb > 0 && d->nb >= 1 && d->nb <= TC_MAXB && d->stride >= 1 && d->stride <= 2,
              "%s: bad dims N=%d T_in=%d V=%d Cb=%d nb=%d stride=%d", who, d->N, d->T_in, d->V, d->Cb, d->nb, d->stride);
     for (int b = 0; b < d->nb; ++b) {
         TG_CHECK(d->w[b], "%s: branch %d has no weights", who, b);
@@ -465,10 +581,16 @@ extern "C" int tamgcn_tconv_fwd(const tamgcn_tconv_desc* d, void* stream) {
     }
     a.ws_m = (long long)d->Cb * d->KT; a.ws_k = d->KT; a.ws_t = 1; a.w_off = 0;
     a.y = d->y; a.yctot = d->yctot; a.ycoff = d->ycoff; a.T_out = T_out;
-    a.stats = d->stats_part; a.stats_ctot = d->stats_ctot; a.nparts = d->N * p.ntt * p.nsl;
+    tc_split(&p, d->N, d->nb * p.mh);
+    a.stats = d->stats_part; a.stats_ctot = d->stats_ctot; a.nparts = d->N * p.ngrp * p.nsl;
     a.mask = null_src(); a.center = nullptr;
-    a.BT = p.BT; a.TIN = p.TIN; a.LB = p.LB; a.pitchX = p.pitchX; a.pitchW = p.pitchW; a.Vs = p.Vs; a.Vp = p.Vp; a.nsl = p.nsl; a.mh = p.mh;
-    dim3 grid(p.ntt * p.nsl, d->nb * p.mh + (d->pool ? 1 : 0), d->N);
+    a.BT = p.BT; a.TIN = p.TIN; a.LB = p.LB; a.Vs = p.Vs; a.Vp = p.Vp; a.nsl = p.nsl; a.mh = p.mh;
+    a.ntiles = p.ngrp * p.nsl; a.nby = d->nb * p.mh; a.ntt = p.ntt; a.tpw = p.tpw;
+    dim3 grid((unsigned)(a.ntiles * a.nby * d->N));
+    if (d->pool) {                                             // first: short, and it leaves the source's rows in L2 for the convolutions
+        hipLaunchKernelGGL(tpool_kernel, dim3((unsigned)(a.ntiles * d->N)), dim3(TC_NT), 0, (hipStream_t)stream, a);
+        TG_LAUNCH_CHECK("tamgcn_tconv_fwd (pooled branch)");
+    }
     if (tc_launch<false>(a, p, d->KT, grid, (hipStream_t)stream)) return -1;
     TG_LAUNCH_CHECK("tamgcn_tconv_fwd");
     return 0;
@@ -500,10 +622,12 @@ extern "C" int tamgcn_tconv_bwd(const tamgcn_tconv_desc* d, void* stream) {
     }
     a.ws_m = d->KT; a.ws_k = (long long)d->Cb * d->KT; a.ws_t = -1; a.w_off = d->KT - 1;
     a.y = d->y; a.yctot = d->yctot; a.ycoff = d->ycoff; a.T_out = d->T_in;
-    a.stats = d->stats_part; a.stats_ctot = d->stats_ctot; a.nparts = d->N * p.ntt * p.nsl;
+    tc_split(&p, d->N, d->nb * p.mh);
+    a.stats = d->stats_part; a.stats_ctot = d->stats_ctot; a.nparts = d->N * p.ngrp * p.nsl;
     a.mask = make_src(*d->mask); a.center = d->center;
-    a.BT = p.BT; a.TIN = p.TIN; a.LB = p.LB; a.pitchX = p.pitchX; a.pitchW = p.pitchW; a.Vs = p.Vs; a.Vp = p.Vp; a.nsl = p.nsl; a.mh = p.mh;
-    dim3 grid(p.ntt * p.nsl, d->nb * p.mh, d->N);
+    a.BT = p.BT; a.TIN = p.TIN; a.LB = p.LB; a.Vs = p.Vs; a.Vp = p.Vp; a.nsl = p.nsl; a.mh = p.mh;
+    a.ntiles = p.ngrp * p.nsl; a.nby = d->nb * p.mh; a.ntt = p.ntt; a.tpw = p.tpw;
+    dim3 grid((unsigned)(a.ntiles * a.nby * d->N));
     if (tc_launch<true>(a, p, d->KT, grid, (hipStream_t)stream)) return -1;
     TG_LAUNCH_CHECK("tamgcn_tconv_bwd");
     return 0;
