@@ -12,12 +12,14 @@ other side of zero in any fp32 evaluation that rounds differently, the ReLU mask
 gradient entry worth 10 % of max|grad| appears or disappears; BatchNorm backward then spreads it
 over the channel.  The reference itself shows the same events between its fp32 and fp64 runs
 (fixture: *64 arrays).  So gradients are checked with flip-robust metrics against the fp64
-reference: relative L2 error <= 5e-2 and cosine similarity >= 0.999.  For the mildest case
-(ucla_t13) the bars are ten times tighter -- relative L2 <= 5e-3 -- and at most 5 % of a tensor's entries may
-leave the max-norm bound (2e-3 * scale + 10 x the reference's own fp32 noise): with one summation
-order of the BatchNorm partial sums the case has no flip at all and the max-norm bound holds everywhere,
-with another (same kernels, 16-lane instead of 256-thread row sums) two of the 1560 entries of dx
-exceed it by 40 % and 16 of the 1200 entries of l3's dPA by up to 60 % while every block, fed the exact inputs, still reproduces its fp64 result to 5e-7
+reference: relative L2 error <= 5e-2 and cosine similarity >= 0.999.  Until round 3 the mildest case (ucla_t13) carried
+ten times tighter bars; it was mild by luck: its fp64 forward has a ReLU input 4.65e-6 from zero at l10's OUTPUT (T = 4
+there: 160 positions per channel), the HIP forward's error at that depth is 2.7e-6 of max|.| ~ 10, and with round 4's
+temporal-branch kernels (csrc/tconv.hip, another summation order) that one mask lands on the other side: l10's input
+gradient moves by 23 % of its max-norm at that position and dx by 1.1e-2, while every block of the case, fed the exact
+inputs, reproduces its fp64 result to 7e-7 and the generic kernels on the same inputs reproduce dx to 6e-6
+(tools/flip_report.py -> profiles/r04_flip_report_ucla_t13.txt).  The case now takes the flip-robust bars like the others and
+its shapes (T = 13 / 7 / 4) joined the teacher-forced strict test instead (tests/test_gpu_blocks.py, BLOCK_CASES)
 (tools/block_report.py, tools/dx_report.py)."""
 import numpy as np
 import pytest
@@ -32,7 +34,7 @@ from tam_gcn_amd.models import ctrgcn as M                                      
 NOISE_K = 10.0
 
 
-STRICT_CASES = ('ucla_t13',)          # mildest case: ten times tighter bars (see the docstring)
+STRICT_CASES = ()                     # see the docstring: ucla_t13 was strict until round 4
 
 
 def _check(name, got, ref32, ref64, rel, atol=0.0, strict=True):

@@ -481,6 +481,10 @@ TCONV_CASES = [
     (2, 32, 15, 25, 5, (1, 2), 2),
     (1, 64, 40, 64, 5, (1, 2), 1),        # V = 64: four joint slices
     (1, 16, 9, 64, 3, (2,), 2),
+    (2, 64, 4, 20, 5, (1, 2), 1),         # the model cases' last layers at T = 13: 4 frames, fewer column tiles than waves
+    (2, 64, 7, 20, 5, (1, 2), 2),
+    (2, 32, 13, 20, 5, (1, 2), 2),
+    (2, 32, 7, 20, 5, (1, 2), 1),
 ]
 
 
