@@ -591,6 +591,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel_vec(const ConvArgs a) {
 //               each B element is read by exactly one wave, so this costs 1-3 VALU per element
 //   epilogue    the staged float4 epilogue of conv_kernel_vec (staged_rows)
 // ===========================================================================
+// x / d for 0 <= x < 2^20, 4 <= d <= 1024 through the reciprocal (three VALU instead of ~25): (x + 0.5) / d is at least
+// 0.5 / d >= 5e-4 away from an integer, float rounding moves it by < 0.07 at these sizes
+__device__ __forceinline__ int tc_like_div(int x, float rcp) { return (int)(((float)x + 0.5f) * rcp); }
+
 constexpr int G_NT = 512, G_BMT = 64, G_PA = 80, G_PBMAX = 320, G_NST = 3, G_CWT = 5, G_MT = 2;
 
 typedef __attribute__((address_space(1))) const void* tg_gptr;
@@ -606,8 +610,14 @@ __device__ __forceinline__ void wait_vmcnt(int n) {     // n is wave-uniform
     }
 }
 
-template <int NSRC, int BK>
-__global__ __launch_bounds__(G_NT, 2) void conv1x1_glds_kernel(const ConvArgs a, int ntt, int nmt) {
+// SW (operand-swapped product): the activation columns are the MFMA rows and the output channels its columns, so a lane's
+// four accumulator registers are FOUR CONSECUTIVE columns of one channel: the epilogue (bias, eval-mode affine, broadcast
+// term, residual adds, ReLU, BatchNorm moments) runs straight from the registers with 16-byte accesses -- no LDS staging
+// passes, none of their four barriers (28 % of a workgroup's lifetime at 64 channels, profiles/r03_conv_phases.txt).  The
+// inner loop is the same (same fragments, operands exchanged).  Launches with a ReLU mask or a centring operand (the k x 1
+// data gradients of ST-GCN) keep the staged form (SW = false).
+template <int NSRC, int BK, bool SW>
+__global__ __launch_bounds__(G_NT, SW ? 4 : 2) void conv1x1_glds_kernel(const ConvArgs a, int ntt, int nmt) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int STG = BK * G_PBMAX * NSRC + BK * G_PA;          // floats per stage
     constexpr int NAI = BK / 8;                                   // A pieces per wave and chunk
@@ -730,7 +740,6 @@ __global__ __launch_bounds__(G_NT, 2) void conv1x1_glds_kernel(const ConvArgs a,
 #pragma unroll
         for (int c = 0; c < G_CWT; ++c) acc[mt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float lo = a.src.act == 1 ? 0.f : -__builtin_inff();
-
     TG_T(tt0);
     const int nch = K / BK;
     // The prologue coefficients are requested FIRST and the whole ring (three chunks) right behind them: vmcnt retires in
@@ -788,11 +797,128 @@ __global__ __launch_bounds__(G_NT, 2) void conv1x1_glds_kernel(const ConvArgs a,
 #pragma unroll
             for (int cc = 0; cc < G_CWT; ++cc)
 #pragma unroll
-                for (int mt = 0; mt < G_MT; ++mt) acc[mt][cc] = mfma16(av[mt], bv[cc], acc[mt][cc]);
+                for (int mt = 0; mt < G_MT; ++mt) acc[mt][cc] = SW ? mfma16(bv[cc], av[mt], acc[mt][cc]) : mfma16(av[mt], bv[cc], acc[mt][cc]);
         }
         TG_T(te); TG_ACC(6, te - td);
     }
     TG_T(tg0);
+
+    if constexpr (SW) {
+        // ---- epilogue from the registers: lane (j, kq) holds, per (row tile mt, column tile c), columns
+        // (wn*CWT + c)*16 + 4*kq + r (r = 0..3) of channel m0 + wm*32 + mt*16 + j.  Every load of the epilogue (per-channel
+        // constants, residual / broadcast operands) is issued and consumed BEFORE the first store: vmcnt retires in order,
+        // a load behind a store waits for that store.
+        const float plo = a.post_act == 1 ? 0.f : -__builtin_inff();
+        const float rV = 1.0f / (float)V;
+        const bool contig = a.ostride == 1;                   // a tile's columns are one contiguous run of the output row
+        const bool vec_y = contig || (V & 3) == 0;             // a group of four columns is one 16-byte access
+        const bool vec_b = (V & 3) == 0;
+        float q1[G_MT], q2[G_MT];
+        unsigned offs[G_MT][G_CWT];                           // element offset of the group inside y (host: < 2^32 elements)
+#pragma unroll
+        for (int mt = 0; mt < G_MT; ++mt) {
+            const int m = m0 + wm * 32 + mt * 16 + j;
+            const bool mok = m < a.M;
+            const int mm = mok ? m : 0;
+            const float bia = a.bias ? a.bias[mm] : 0.f;
+            const float pc1 = a.post_coef ? a.post_coef[a.ycoff + mm] : 1.f, pc0 = a.post_coef ? a.post_coef[2 * a.post_ctot + a.ycoff + mm] : 0.f;
+            const unsigned ybase = (unsigned)(((long long)n * a.yctot + a.ycoff + mm) * a.T_y * V);
+            const float* bc = a.bcast ? a.bcast + ((long long)mm * a.N + n) * V : nullptr;
+            float p1 = 0.f, p2 = 0.f;
+            f32x4 t1[G_CWT], t2[G_CWT];
+#pragma unroll
+            for (int c = 0; c < G_CWT; ++c) {                 // unconditional loads: an inactive group re-reads the tile's first one
+                const int col0 = (wn * G_CWT + c) * 16 + 4 * kq;
+                const int cs_ = (mok && col0 + 4 <= ncols) ? col0 : 0;
+                const int fr = tc_like_div(cs_, rV), v = cs_ - fr * V;
+                offs[mt][c] = ybase + (unsigned)(contig ? t0 * V + cs_ : (t0 + fr) * a.ostride * V + v);
+                t1[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                t2[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (vec_y) {
+                    if (a.add1) t1[c] = *reinterpret_cast<const f32x4*>(a.add1 + offs[mt][c]);
+                    if (a.add2) t2[c] = *reinterpret_cast<const f32x4*>(a.add2 + offs[mt][c]);
+                }
+                if (bc && vec_b) {
+                    const f32x4 tb = *reinterpret_cast<const f32x4*>(bc + v);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t2[c][r] = fmaf(tb[r], a.bcast_scale, t2[c][r]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < G_CWT; ++c) {
+                const int col0 = (wn * G_CWT + c) * 16 + 4 * kq;
+                f32x4 val = acc[mt][c];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) val[r] = fmaf(pc1, val[r] + bia, pc0);
+                if (mok && col0 + 4 <= ncols && vec_y && (!bc || vec_b)) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) val[r] = fmaxf(val[r] + t1[c][r] + t2[c][r], plo);
+                    p1 += (val[0] + val[1]) + (val[2] + val[3]);
+                    p2 = fmaf(val[0], val[0], fmaf(val[1], val[1], fmaf(val[2], val[2], fmaf(val[3], val[3], p2))));
+                } else if (mok && col0 < ncols) {
+                    // element-wise: the tile's last, partial group; rows of V % 4 != 0 joints with a strided output or a
+                    // broadcast term (a group may leave its frame).  Finished here, stored below with the others.
+                    for (int r = 0; r < 4 && col0 + r < ncols; ++r) {
+                        const int ci = col0 + r, fi = tc_like_div(ci, rV), vi = ci - fi * V;
+                        const unsigned o = ybase + (unsigned)(contig ? t0 * V + ci : (t0 + fi) * a.ostride * V + vi);
+                        float x = val[r];
+                        if (bc) x = fmaf(bc[vi], a.bcast_scale, x);
+                        if (a.add1) x += a.add1[o];
+                        if (a.add2) x += a.add2[o];
+                        x = fmaxf(x, plo);
+                        val[r] = x;
+                        p1 += x;
+                        p2 = fmaf(x, x, p2);
+                    }
+                }
+                acc[mt][c] = val;
+            }
+            q1[mt] = p1; q2[mt] = p2;
+        }
+        // the stores, all of them behind the last load
+#pragma unroll
+        for (int mt = 0; mt < G_MT; ++mt) {
+            const bool mok = m0 + wm * 32 + mt * 16 + j < a.M;
+#pragma unroll
+            for (int c = 0; c < G_CWT; ++c) {
+                const int col0 = (wn * G_CWT + c) * 16 + 4 * kq;
+                if (!mok || col0 >= ncols) continue;
+                if (col0 + 4 <= ncols && vec_y) *reinterpret_cast<f32x4*>(a.y + offs[mt][c]) = acc[mt][c];
+                else {
+                    const unsigned ybase = (unsigned)(((long long)n * a.yctot + a.ycoff + m0 + wm * 32 + mt * 16 + j) * a.T_y * V);
+                    for (int r = 0; r < 4 && col0 + r < ncols; ++r) {
+                        const int ci = col0 + r, fi = tc_like_div(ci, rV), vi = ci - fi * V;
+                        a.y[ybase + (unsigned)(contig ? t0 * V + ci : (t0 + fi) * a.ostride * V + vi)] = acc[mt][c][r];
+                    }
+                }
+            }
+        }
+        if (a.stats_part) {
+            // row moments: the four kq lanes of a channel, then the four column waves through LDS (the ring is dead)
+            __syncthreads();
+            float* Sd = smem;                                 // [2][4][64]
+#pragma unroll
+            for (int mt = 0; mt < G_MT; ++mt) {
+                float u1 = q1[mt], u2 = q2[mt];
+                u1 += __shfl_xor(u1, 16); u1 += __shfl_xor(u1, 32);
+                u2 += __shfl_xor(u2, 16); u2 += __shfl_xor(u2, 32);
+                if (kq == 0) {
+                    Sd[(0 * 4 + wn) * G_BMT + wm * 32 + mt * 16 + j] = u1;
+                    Sd[(1 * 4 + wn) * G_BMT + wm * 32 + mt * 16 + j] = u2;
+                }
+            }
+            __syncthreads();
+            if (tid < 2 * G_BMT) {
+                const int stt = tid / G_BMT, row = tid - stt * G_BMT;
+                const int m = m0 + row;
+                const float tot = (Sd[(stt * 4 + 0) * G_BMT + row] + Sd[(stt * 4 + 1) * G_BMT + row]) +
+                                  (Sd[(stt * 4 + 2) * G_BMT + row] + Sd[(stt * 4 + 3) * G_BMT + row]);
+                if (m < a.M) a.stats_part[((long long)stt * a.stats_ctot + a.stats_coff + m) * a.nparts + g] = tot;
+            }
+        }
+        TG_T(tg1s); TG_ACC(7, tg1s - tg0); TG_ACC(8, tg1s - tt0); TG_ACC(9, 1);
+        return;
+    }
 
     // ---- staged epilogue (two passes of 32 rows through the dead stage buffers)
     constexpr int PT = G_CWT * 64 + 4, RP = 32;
@@ -1203,19 +1329,26 @@ extern "C" int tamgcn_conv(const tamgcn_conv_desc* d, void* stream) {
     } else if (glds) {
         const int nmt = ceil_div(d->M, G_BMT);
         const unsigned nblk = (unsigned)(d->N * p.ntt * nmt);
-        if (d->src.x2) {
-            static tg_devmask f2 = 0;
-            const size_t lds = glds_lds_bytes<2, 8>(d->K);
-            tg_allow_lds((const void*)conv1x1_glds_kernel<2, 8>, 160 * 1024, &f2);
-            hipLaunchKernelGGL((conv1x1_glds_kernel<2, 8>), dim3(nblk), dim3(G_NT), lds, (hipStream_t)stream, a, p.ntt, nmt);
-            tamgcn_note_kernel("conv1x1_glds_kernel<2, 8>");
-        } else {
-            static tg_devmask f1 = 0;
-            const size_t lds = glds_lds_bytes<1, 16>(d->K);
-            tg_allow_lds((const void*)conv1x1_glds_kernel<1, 16>, 160 * 1024, &f1);
-            hipLaunchKernelGGL((conv1x1_glds_kernel<1, 16>), dim3(nblk), dim3(G_NT), lds, (hipStream_t)stream, a, p.ntt, nmt);
-            tamgcn_note_kernel("conv1x1_glds_kernel<1, 16>");
+        // The register epilogue (operand-swapped product) is an OPT-IN (TAMGCN_CONV_SWAP=1): built for VERDICT r03 item 4 and
+        // measured against the staged epilogue at the step's eleven signatures (tools/conv_swap_bench.py,
+        // profiles/r04_conv_swap_ab.txt, two interleaved rounds): forward convs with moments 0 .. +1 % (no change), two-source
+        // data gradients 10-17 % SLOWER (62 -> 72 us at 64 channels), the K >= 384 dx GEMMs with a broadcast term and two
+        // residual adds 5 % faster, the K = 192 one 3 % slower.  With two workgroups per CU a workgroup's staged epilogue runs
+        // under the other's MFMAs; it was never on the critical path.
+        static int sw_env = -1;
+        if (sw_env < 0) { const char* e = getenv("TAMGCN_CONV_SWAP"); sw_env = e ? atoi(e) : 0; }
+        const bool sw = sw_env != 0 && !d->mask && !d->aux;
+#define TG_GLDS_CASE(NS_, BK_, SW_)                                                                                       \
+        {                                                                                                                   \
+            static tg_devmask fl = 0;                                                                                       \
+            const size_t lds = glds_lds_bytes<NS_, BK_>(d->K);                                                              \
+            tg_allow_lds((const void*)conv1x1_glds_kernel<NS_, BK_, SW_>, 160 * 1024, &fl);                                 \
+            hipLaunchKernelGGL((conv1x1_glds_kernel<NS_, BK_, SW_>), dim3(nblk), dim3(G_NT), lds, (hipStream_t)stream, a, p.ntt, nmt); \
+            tamgcn_note_kernel("conv1x1_glds_kernel<%d, %d%s>", NS_, BK_, SW_ ? ", swapped" : "");                          \
         }
+        if (d->src.x2) { if (sw) TG_GLDS_CASE(2, 8, true) else TG_GLDS_CASE(2, 8, false) }
+        else { if (sw) TG_GLDS_CASE(1, 16, true) else TG_GLDS_CASE(1, 16, false) }
+#undef TG_GLDS_CASE
     } else if (p.vec) {
         dim3 gridv(p.ntt * p.nsl, ceil_div(d->M, 16 * p.mt), d->N);
 #define TG_CONV_CASE(BKV_, MT_, CW_)                                                                              \

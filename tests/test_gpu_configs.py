@@ -327,3 +327,56 @@ def test_config4_full_size_properties():
     for k, p in blk.named_parameters():                     # (biases in front of a train-mode BatchNorm: exact-zero gradients,
         n1 = float(g1[k].norm())                            # rounding noise only -- hence the floor)
         assert float((g1[k] - p.grad).norm()) <= 5e-3 * n1 + 1e-4 * gmax, k
+
+
+def test_config4_at_its_stated_size_256_clips():
+    """BASELINE configs[4] at the per-GPU size it states: ONE TCN_GCN_unit(256, 256) on (256, 256, 512, 64) -- 8.6 GB per
+    activation, x3 = conv3(x) has 6.4e9 elements, so the calls are split over clips by ops.n_chunks WITHOUT the test forcing it
+    (the un-forced path had never run).  (1) eval mode: clips 100..101 of the 256-clip launch equal the
+    same two clips launched alone; (2) train mode: forward + backward finite, and permuting the batch leaves every parameter
+    gradient unchanged (fp32 summation-order noise) -- the chunked launches cover every clip exactly once."""
+    from helpers import A_BY_V
+    from tam_gcn_amd import ops
+    dev = torch.device('cuda:0')
+    free, total = torch.cuda.mem_get_info()
+    if total < 250 * 2 ** 30:
+        pytest.skip('needs a 288 GB MI355X')
+    C, T, V, NB = 256, 512, 64, 256
+    assert NB * 3 * C * T * V > ops.CHUNK_ELEMS          # x3 really exceeds one launch
+    torch.manual_seed(0)
+    blk = M.TCN_GCN_unit(C, C, A_BY_V[V])
+    fill_state_(blk.state_dict(), seed=77)
+    blk = blk.to(dev)
+    gen = torch.Generator(device=dev).manual_seed(13)
+    x = torch.rand(NB, C, T, V, generator=gen, device=dev) * 2 - 1
+    blk.eval()
+    with torch.no_grad():
+        full = blk(x)
+        sub = blk(x[100:102].contiguous())
+        assert torch.isfinite(full).all()
+        scale = float(full.abs().max())
+        assert float((full[100:102] - sub).abs().max()) <= 1e-4 * scale
+    del full, sub
+    blk.train()
+    cot = torch.rand(NB, C, T, V, generator=gen, device=dev) * 2 - 1
+    xr = x.requires_grad_(True)
+    out = blk(xr)
+    out.backward(cot)
+    assert torch.isfinite(out.detach()).all() and torch.isfinite(xr.grad).all()
+    g1 = {k: p.grad.clone() for k, p in blk.named_parameters()}
+    del out
+    xr.grad = None
+    for p in blk.parameters():
+        p.grad = None
+    perm = torch.randperm(NB, generator=torch.Generator().manual_seed(5)).to(dev)
+    xp = x.detach()[perm].contiguous().requires_grad_(True)
+    del xr, x
+    cp = cot[perm].contiguous()
+    del cot
+    outp = blk(xp)
+    outp.backward(cp)
+    torch.cuda.synchronize()
+    gmax = max(float(v.norm()) for v in g1.values())
+    for k, p in blk.named_parameters():
+        assert torch.isfinite(p.grad).all(), k
+        assert float((g1[k] - p.grad).norm()) <= 5e-3 * float(g1[k].norm()) + 1e-4 * gmax, k

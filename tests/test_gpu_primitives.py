@@ -341,6 +341,22 @@ def test_split_fp32_modes_against_fp64(mode, bar):
         assert max(errs['wgrad']) > 1e-6
 
 
+def test_pointwise_gemm_register_epilogue_variant():
+    """TAMGCN_CONV_SWAP=1 (read once per process): the 1x1 LDS-DMA GEMM as an operand-swapped product with its epilogue
+    straight from the accumulators -- kept as an opt-in after it measured no faster (csrc/conv.hip, profiles/r04_conv_swap_ab.txt).
+    The conv / pointwise primitive tests of this file, in a child process with the switch on."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get('TAMGCN_CONV_SWAP') == '1':
+        pytest.skip('already inside the child run')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-m', 'gpu', '-x', '-q', '-k',
+                          'conv_fwd_bwd_wgrad or pointwise_dma or prologue_slices'], cwd=root,
+                         env=dict(os.environ, TAMGCN_CONV_SWAP='1'), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
+
+
 @pytest.mark.parametrize('shape,training', [((3, 3, 7, 25, 2), True), ((4, 3, 13, 20, 1), True), ((3, 3, 7, 25, 2), False)])
 def test_stem_and_head_against_torch(shape, training):
     """data_bn + permutes (reference models/ctrgcn.py:328-332) and mean-pool + fc (:343-348) against the
@@ -553,3 +569,66 @@ def test_tconv_fused_branches_fwd_bwd(case):
     hc = (h1.double() - mu.double()[None, :, None, None])[:, lead: lead + nb * Cb]
     assert float((bs_[0] - dref.sum((0, 2, 3))).abs().max()) <= 2e-6 * dscale * cnt1
     assert float((bs_[1] - (dref * hc).sum((0, 2, 3))).abs().max()) <= 4e-6 * dscale * float(hc.abs().max()) * cnt1
+
+
+def test_de_tail_r16_bit_identical_beside_other_streams_in_a_graph():
+    """VERDICT r03 item 6 / ADVICE r03: the captured multi-stream step of round 3 was once ~1e-4 off in ONE model's
+    gradients.  The records (gpurun_out r03c/r03d/r03e logs, quoted in DESIGN.md section 3) localise every occurrence to a
+    128-input-channel block (l7 or l8: R = 16 rel-channels) with exactly two of that block's own tensors affected -- one
+    subset's dp or dq -- i.e. to the dE chain of the R = 16 shape, whose tail is still ctrgc_de_tail_reg_kernel.  This test
+    puts that chain (dE accumulation + tail + slab reductions) for FOUR independent problems on four streams inside ONE HIP
+    graph, beside each other and beside a bandwidth-heavy neighbour, and requires every replay to be bit-identical to the
+    same four problems run one after the other eagerly."""
+    from tam_gcn_amd import ops
+    from tam_gcn_amd.ops import S
+    d = dev()
+    N, Cin, Cout, T, V, S_, R = 16, 128, 128, 32, 20, 3, 16
+    probs = []
+    for i in range(4):
+        t = lambda z: z.to(d).contiguous()
+        x = t(rnd((N, Cin, T, V), 100 + i))
+        pq = t(rnd((S_ * 2 * R, N, V), 110 + i))
+        W3, B3 = t(rnd((S_ * Cout, Cin), 120 + i) * (1.0 / Cin ** 0.5)), t(rnd((S_ * Cout,), 130 + i) * 0.1)
+        W4, B4 = t(rnd((S_, Cout, R), 140 + i) * (1.0 / R ** 0.5)), t(rnd((S_, Cout), 150 + i) * 0.1)
+        A, alpha = t(rnd((S_, V, V), 160 + i) * 0.3), torch.tensor([0.7], device=d)
+        dy = t(rnd((N, Cout, T, V), 170 + i))
+        x3 = t(rnd((N, S_ * Cout, T, V), 180 + i))
+        probs.append((x, pq, W3, B3, W4, B4, A, alpha, dy, x3))
+
+    def chain(p):
+        x, pq, W3, B3, W4, B4, A, alpha, dy, x3 = p
+        return ops.ctrgc_bwd_de(S(x), pq, W3, B3, W4, B4, A, alpha, Cin, Cout, S_, R, S(dy), x3)
+
+    ref = [[o.clone() for o in chain(p)] for p in probs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(d) for _ in range(4)]
+    big = torch.randn(64 * 1024 * 1024 // 4, device=d)
+
+    def step():
+        cur = torch.cuda.current_stream()
+        outs = []
+        for st, p in zip(streams, probs):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                outs.append(chain(p))
+        junk = big * 1.0001 + 1.0                                               # a streaming neighbour on the origin stream
+        for st in streams:
+            cur.wait_stream(st)
+        return outs, junk
+
+    s0 = torch.cuda.Stream(d)
+    s0.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s0):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(s0)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        outs, _ = step()
+    for rep in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        for i, (got, want) in enumerate(zip(outs, ref)):
+            for nm, a_, b_ in zip(('dA', 'dW4', 'db4', 'dalpha', 'dpq'), got, want):
+                assert torch.equal(a_, b_), f'replay {rep}, problem {i}: {nm} differs by {float((a_ - b_).abs().max()):.3e}'
