@@ -145,6 +145,106 @@ class FlatGradBucket:
         return self.flat
 
 
+class SegmentedReducer:
+    """The gradient exchange of a FlatGradBucket in `nseg` contiguous segments, each all-reduced on a communication stream
+    AS SOON AS backward has produced its last gradient ("2-3 buckets overlapped with backward").
+
+    Backward reaches the blocks l10 -> l1, i.e. the bucket from its END to its start (the arena / bucket order follows
+    ``model.modules()``: data_bn, l1, ..., l10, fc), so segment 0 is the TAIL of the flat buffer and completes first.  A
+    post-accumulate hook on every parameter counts its segment down; the hook of a segment's last gradient packs that
+    segment into the bucket (one multi-tensor copy, ``p.grad`` re-pointed at the bucket's views) and starts its all-reduce
+    on the communication stream behind an event; ``finish()`` packs what is left (parameters that received no gradient),
+    joins the communication stream and applies the mean.  Element for element the same sums as ONE all-reduce of the whole
+    bucket (tests/test_distributed_cpu.py holds the two bit-equal on gloo).
+
+    Eager launches only: under HIP-graph replay no Python (and no hook) runs, the step's two graphs keep ONE all-reduce
+    between them (bench.py), which at 6.8 MB is ~0.15 ms of a ~31 ms step."""
+
+    def __init__(self, bucket, nseg=3, group=None, comm_stream=None):
+        self.bucket, self.group = bucket, group
+        n = len(bucket.params)
+        nseg = max(1, min(int(nseg), n))
+        # contiguous runs of parameters with about equal element counts, taken from the END of the bucket
+        total = sum(p.numel() for p in bucket.params)
+        bounds, acc, target = [n], 0, total / nseg
+        for i in range(n - 1, 0, -1):
+            acc += bucket.params[i].numel()
+            if acc >= target * len(bounds) and len(bounds) < nseg:
+                bounds.append(i)
+        bounds.append(0)
+        self.ranges = [(bounds[k + 1], bounds[k]) for k in range(len(bounds) - 1)]       # segment k = params[lo:hi], k = 0 is the tail
+        self.seg_of = {}
+        for k, (lo, hi) in enumerate(self.ranges):
+            for i in range(lo, hi):
+                self.seg_of[id(bucket.params[i])] = k
+        ends = [bucket.offsets[hi] if hi < n else bucket.flat.numel() for _, hi in self.ranges]
+        self.flat_ranges = [(bucket.offsets[lo], e) for (lo, _), e in zip(self.ranges, ends)]
+        self.comm = comm_stream
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in bucket.params]
+        self.begin()
+
+    def begin(self):
+        """Call before every backward (after ``bucket.zero()``)."""
+        self.left = [hi - lo for lo, hi in self.ranges]
+        self.sent = [False] * len(self.ranges)
+        self.scale = None
+
+    def _distributed(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def _pack(self, k):
+        lo, hi = self.ranges[k]
+        b = self.bucket
+        pairs = [(b.views[i], b.params[i].grad) for i in range(lo, hi)]
+        f0, f1 = self.flat_ranges[k]
+        if any(g is None for _, g in pairs):
+            b.flat[f0:f1].zero_()
+        live = [(v, g) for v, g in pairs if g is not None and g.data_ptr() != v.data_ptr()]
+        if live:
+            torch._foreach_copy_([v for v, _ in live], [g for _, g in live])
+        for i in range(lo, hi):
+            b.params[i].grad = b.views[i]
+
+    def _send(self, k, local_n=None, global_n=None):
+        self._pack(k)
+        self.sent[k] = True
+        if not self._distributed():
+            return
+        f0, f1 = self.flat_ranges[k]
+        seg = self.bucket.flat[f0:f1]
+        if self.comm is not None and seg.is_cuda:
+            self.comm.wait_stream(torch.cuda.current_stream(seg.device))
+            with torch.cuda.stream(self.comm):
+                dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group)
+
+    def _on_grad(self, p):
+        k = self.seg_of.get(id(p))
+        if k is None or self.sent[k]:
+            return
+        self.left[k] -= 1
+        if self.left[k] == 0:
+            self._send(k)
+
+    def finish(self):
+        """Segments whose hooks did not all fire (unused parameters) go now; join the communication stream; mean."""
+        for k in range(len(self.ranges)):
+            if not self.sent[k]:
+                self._send(k)
+        flat = self.bucket.flat
+        if self.comm is not None and flat.is_cuda:
+            torch.cuda.current_stream(flat.device).wait_stream(self.comm)
+        if self._distributed():
+            flat.div_(dist.get_world_size(self.group))
+        return flat
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
 def broadcast_state(module, src=0, group=None, arena=None):
     """Make every replica start from rank ``src``'s parameters and buffers.
 

@@ -224,8 +224,83 @@ def test_bench_self_launches_two_ranks_rehearsal():
     assert r4.returncode == 0, r4.stderr.decode()[-2000:]
     js4 = json.loads([ln for ln in r4.stdout.decode().splitlines() if ln.startswith('{')][0])
     assert js4['n_gpus'] == 2 and js4['config']['streams'] == 4 and js4['config']['global_batch'] == 256 and js4['value'] is None
+    # the segmented, overlapped exchange (distributed.SegmentedReducer) in the same control flow: eager launches, three segments;
+    # the stand-in gradients are rank-dependent constants, so the final "loss" and the parameters after the flat SGD steps must
+    # equal the one-bucket run's exactly
+    ro = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                         '--overlap-allreduce', '3'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert ro.returncode == 0, ro.stderr.decode()[-2000:]
+    jso = json.loads([ln for ln in ro.stdout.decode().splitlines() if ln.startswith('{')][0])
+    assert jso['n_gpus'] == 2 and jso['config']['allreduce'].startswith('3 segments') and jso['config']['launch'] == 'eager'
+    assert js['config']['allreduce'].startswith('one flat bucket')
+    ro4 = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--config', '4stream',
+                          '--overlap-allreduce', '3'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert ro4.returncode == 0, ro4.stderr.decode()[-2000:]
     # a launcher environment that disagrees with --gpus is an error, not silently ignored
     env2 = dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
     r2 = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'], env=env2, stdout=subprocess.PIPE,
                         stderr=subprocess.PIPE, timeout=600)
     assert r2.returncode != 0 and b'WORLD_SIZE=1' in r2.stderr
+
+
+def _segment_worker(rank, world, port, out):
+    """The real Model's parameters in a ParamArena; gradients arrive through autograd (a surrogate loss whose gradient w.r.t.
+    every parameter is a seeded rank-dependent tensor), so the post-accumulate hooks fire as in a real backward."""
+    from tam_gcn_amd.distributed import ParamArena, SegmentedReducer
+    from tam_gcn_amd.models.ctrgcn import Model
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(0)
+    models = torch.nn.ModuleList([Model(num_class=10, num_point=20, num_person=1, graph='graph.ucla.Graph',
+                                        graph_args=dict(labeling_mode='spatial')) for _ in range(2)])     # two models, one arena
+    arena = ParamArena(models)
+    bucket = arena.grad_bucket()
+    g = torch.Generator().manual_seed(50 + rank)
+    coefs = [torch.randn(p.shape, generator=g) for p in arena.params]
+
+    def backward(skip=()):
+        bucket.zero()
+        loss = sum((p * c).sum() for i, (p, c) in enumerate(zip(arena.params, coefs)) if i not in skip)
+        return loss
+
+    # reference: everything packed after backward, ONE all-reduce
+    backward().backward()
+    bucket.pack()
+    ref = bucket.all_reduce_mean().clone()
+    # segmented: hooks pack and reduce each segment as its last gradient arrives
+    red = SegmentedReducer(bucket, nseg=3)
+    assert len(red.ranges) == 3 and red.ranges[0][1] == len(arena.params) and red.ranges[-1][0] == 0
+    loss = backward()
+    red.begin()
+    loss.backward()
+    assert all(red.sent)                                   # every segment left during backward
+    got = red.finish().clone()
+    # parameters without a gradient this step (a frozen branch): their segments leave in finish(), their slots are zero
+    skip = {0, 1, len(arena.params) - 1}
+    loss = backward(skip)
+    red.begin()
+    loss.backward()
+    assert not all(red.sent)
+    got2 = red.finish().clone()
+    bucket.zero()
+    backward(skip).backward()
+    bucket.pack()
+    ref2 = bucket.all_reduce_mean().clone()
+    red.remove()
+    out[rank] = (bool(torch.equal(got, ref)), bool(torch.equal(got2, ref2)), float(ref.abs().sum()),
+                 [int(hi - lo) for lo, hi in red.ranges])
+    dist.destroy_process_group()
+
+
+def test_segmented_overlapped_allreduce_equals_the_single_allreduce():
+    """the bucket in three contiguous segments (tail first, the order backward completes them), each
+    all-reduced when its last gradient has been packed: bit-equal to one all-reduce of the whole bucket, on two gloo ranks,
+    with one arena over TWO models (the 4-stream configuration's layout) and with parameters that receive no gradient."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_segment_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for r in range(world):
+        same, same2, mass, sizes = out[r]
+        assert same and same2 and mass > 0, out[r]
+        assert len(sizes) == 3 and min(sizes) > 0
