@@ -338,9 +338,12 @@ int tamgcn_maxpool_bwd(const tamgcn_src* gy, const tamgcn_src* src, const float*
 
 /* out = act( a + res ), a = prologue value of `a`, res = NULL | src (identity or coef-applied
  * conv residual); models/ctrgcn.py:145-146 and :283.  rowmean: NULL | [N][C], the mean over (t, v) of every
- * output row -- the last block hands the model head its pooling input (models/ctrgcn.py:343-345) this way. */
+ * output row -- the last block hands the model head its pooling input (models/ctrgcn.py:343-345) this way.
+ * xbar: NULL | [C][N][V], the mean over t of `out` -- the NEXT block's pooled joint-embedding input (what tamgcn_tmean
+ * computes, models/ctrgcn.py:172-174), taken while the row is in registers; needs V % 4 == 0, V <= 64, 16-byte aligned
+ * operands and rowmean == NULL. */
 int tamgcn_add_act_fwd(const tamgcn_src* a, const tamgcn_src* res, int relu,
-                       int N, int C, int T, int V, float* out, float* rowmean, void* stream);
+                       int N, int C, int T, int V, float* out, float* rowmean, float* xbar, void* stream);
 /* dz = dout * (out>0) (relu=1; dz may be NULL when relu=0 and only sums are wanted);
  * part[0..1] = (sum dz, sum dz*a_pre), part[2..3] = (sum dz, sum dz*r_pre) if r_pre given. */
 int tamgcn_add_act_bwd(const float* dout, const float* out, int relu, const float* a_pre, const float* a_save,

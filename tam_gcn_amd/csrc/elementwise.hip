@@ -6,6 +6,7 @@
 // [stat][C][N] slabs (deterministic, finalised in fp64 by bn.hip).
 // Reference: models/ctrgcn.py:117 (max-pool), :145-146, :256-261, :283.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -264,6 +265,94 @@ __global__ __launch_bounds__(EW_THREADS) void maxpool_bwd_kernel(RowGeo geo, Src
     if (part) row_store_sums(s, 2, part, dctot, N, dcoff + c, n, geo, li, rowok);
 }
 
+// The same gradient for V % 4 == 0 and stride 1 or 2 without LDS and without a barrier: a lane owns groups of four
+// consecutive joints of one frame th and requests, in ONE batch, the five source rows th-2 .. th+2 a decision can depend on
+// (an element is the first arg-max of window t only if it beats t's other two candidates) and the gradient rows of the
+// windows that contain th (t = th-1, th, th+1 at stride 1; th/2 or (th -+ 1)/2 at stride 2), both operands through their
+// prologues; every load is unconditional (rows outside the tensor re-read row th and are ignored).  L1 / L2 serve the
+// overlapping rows, HBM sees every tensor once.  (The staged kernel above ran at a quarter of the streaming rate:
+// 58-70 us for 84 MB at 256 clips, profiles/r04a_step_breakdown.txt.)
+template <int STRIDE>
+__global__ __launch_bounds__(EW_THREADS) void maxpool_bwd_vec_kernel(RowGeo geo, SrcDev gy, SrcDev src, const float* src_save, int C, int T_in, int T_out,
+                                                                     int V, float* d, int dctot, int dcoff, int N, float* part) {
+    int c, n, li;
+    const bool rowok = row_coords(geo, C, c, n, li);
+    const int V4 = V >> 2;
+    const int ngrp = rowok ? T_in * V4 : 0;
+    const long long bs = ((long long)n * src.ctot + src.coff + c) * T_in * V;
+    const long long bg = ((long long)n * gy.ctot + gy.coff + c) * T_out * V;
+    float* dp = d + ((long long)n * dctot + dcoff + c) * T_in * V;
+    const int sch = src.coff + c, gch = gy.coff + c;
+    const float sc1 = src.coef ? src.coef[sch] : 1.f, sc0 = src.coef ? src.coef[2 * src.ctot + sch] : 0.f;
+    const float gc1 = gy.coef ? gy.coef[gch] : 1.f, gc2 = (gy.coef && gy.x2) ? gy.coef[gy.ctot + gch] : 0.f,
+                gc0 = gy.coef ? gy.coef[2 * gy.ctot + gch] : 0.f;
+    const float mu = src_save[sch];
+    const float* g2p = gy.x2 ? gy.x2 : gy.x1;
+    const float rV4 = 1.0f / (float)V4;
+    float s[2] = {0.f, 0.f};
+    for (int g = li; g < ngrp; g += geo.tpr) {
+        const int th = (int)(((float)g + 0.5f) * rV4), v = (g - th * V4) << 2;
+        // source rows th-2 .. th+2 (activated), raw centre row for the centred moment
+        float4 xr[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int tt = th + k - 2;
+            const int tc = (tt >= 0 && tt < T_in) ? tt : th;
+            xr[k] = *reinterpret_cast<const float4*>(src.x1 + bs + (long long)tc * V + v);
+        }
+        // gradient rows of the windows that contain th
+        constexpr int NWIN = STRIDE == 1 ? 3 : 2;
+        int wt[NWIN];
+        if (STRIDE == 1) { wt[0] = th - 1; wt[1] = th; wt[2] = th + 1; }
+        else if (th & 1) { wt[0] = (th - 1) >> 1; wt[1] = (th + 1) >> 1; }
+        else { wt[0] = th >> 1; wt[1] = -1; }
+        float4 g1[NWIN], g2[NWIN];
+#pragma unroll
+        for (int w = 0; w < NWIN; ++w) {
+            const int tc = (wt[w] >= 0 && wt[w] < T_out) ? wt[w] : 0;
+            g1[w] = *reinterpret_cast<const float4*>(gy.x1 + bg + (long long)tc * V + v);
+            g2[w] = *reinterpret_cast<const float4*>(g2p + bg + (long long)tc * V + v);
+        }
+        float xa[5][4];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int tt = th + k - 2;
+            const bool ok = tt >= 0 && tt < T_in;
+            const float raw[4] = {xr[k].x, xr[k].y, xr[k].z, xr[k].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float val = fmaf(sc1, raw[e], sc0);
+                if (src.act == 1) val = fmaxf(val, 0.f);
+                xa[k][e] = ok ? val : -INFINITY;                       // outside the tensor: never a candidate
+            }
+        }
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < NWIN; ++w) {
+            const bool wok = wt[w] >= 0 && wt[w] < T_out;
+            const int ctr = wt[w] * STRIDE - th + 2;                   // index of the window's centre row in xa (1, 2 or 3)
+            const float ga[4] = {g1[w].x, g1[w].y, g1[w].z, g1[w].w}, gb[4] = {g2[w].x, g2[w].y, g2[w].z, g2[w].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x0 = xa[2][e];
+                // window t's candidates are rows ctr-1, ctr, ctr+1 of xa in frame order, th is row 2.  aten keeps the FIRST
+                // maximum: th wins iff every earlier candidate is strictly smaller and no later one is greater (a candidate
+                // outside the tensor is -inf and satisfies both).
+                bool win;
+                if (ctr == 1) win = xa[0][e] < x0 && xa[1][e] < x0;
+                else if (ctr == 2) win = xa[1][e] < x0 && !(xa[3][e] > x0);
+                else win = !(xa[3][e] > x0) && !(xa[4][e] > x0);
+                if (wok && win && x0 > 0.f) o[e] += fmaf(gc1, ga[e], fmaf(gc2, gb[e], gc0));
+            }
+        }
+        *reinterpret_cast<float4*>(dp + (long long)th * V + v) = make_float4(o[0], o[1], o[2], o[3]);
+        const float rawc[4] = {xr[2].x, xr[2].y, xr[2].z, xr[2].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s[0] += o[e]; s[1] = fmaf(o[e], rawc[e] - mu, s[1]); }
+    }
+    if (part) row_store_sums(s, 2, part, dctot, N, dcoff + c, n, geo, li, rowok);
+}
+
 // ---- residual add (+ReLU) -------------------------------------------------
 // rowmean != nullptr: also the mean of every output row (the last block's contribution to the model head's pooling,
 // models/ctrgcn.py:343-345, taken while the row is in registers)
@@ -353,6 +442,49 @@ __global__ __launch_bounds__(EW_THREADS) void apply_kernel(RowGeo geo, SrcDev sr
     const long long bs = ((long long)n * src.ctot + src.coff + c) * L;
     float* yp = y + ((long long)n * yctot + ycoff + c) * L;
     for (int i = li; i < L; i += geo.tpr) yp[i] = src_value(src, bs + i, src.coff + c);
+}
+
+// out = act(a + res) AND xbar[c][n][v] = mean_t out(n,c,t,v), the next block's pooled joint embedding input (reference
+// models/ctrgcn.py:172-174: conv1 / conv2 commute with the mean over T), in the pass that writes `out`: V % 4 == 0, V <= 64.
+// 16 lanes per (n, c) row; lane l = f * V4 + g owns the 16-byte joint group g of the frames f, f + F, f + 2F, ... (F = 16 / V4
+// whole frames per step of the group: 240 contiguous bytes at V = 20), so its partial sum is ONE float4 and the sum over the F
+// frame phases is a fixed-order chain of shuffles: deterministic, graph replay = eager bit for bit.
+__global__ __launch_bounds__(EW_THREADS) void add_act_fwd_tmean_kernel(SrcDev a, SrcDev res, int has_res, int relu, int N, int C, int T, int V,
+                                                                       float* out, float* xbar) {
+    const int row = blockIdx.x * (EW_THREADS / 16) + (threadIdx.x >> 4), l = threadIdx.x & 15;
+    const int V4 = V >> 2, F = 16 / V4;
+    const bool rowok = row < N * C;
+    const int r = rowok ? row : 0;
+    const int n = r / C, c = r - n * C;
+    const int f = l / V4, g = l - f * V4;
+    const bool lane_on = rowok && f < F;
+    const int L = T * V;
+    const RowSrc ra = row_src(a, ((long long)n * a.ctot + a.coff + c) * L, a.coff + c);
+    RowSrc rr = ra;
+    if (has_res) rr = row_src(res, ((long long)n * res.ctot + res.coff + c) * L, res.coff + c);
+    float* op = out + ((long long)n * C + c) * L;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane_on) {
+        for (int t = f; t < T; t += F) {
+            const int i4 = t * V4 + g;
+            float4 v = row_val4(ra, i4);
+            if (has_res) { const float4 q = row_val4(rr, i4); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            reinterpret_cast<float4*>(op)[i4] = v;
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    // frame phases 1 .. F-1 into phase 0, in order (every lane of the wave takes part in the shuffles)
+    float4 tot = acc;
+    for (int ff = 1; ff < F; ++ff) {
+        const int srcl = (threadIdx.x & 48) + ff * V4 + g;           // same 16-lane group (lane & 48 = its base inside the wave)
+        const float px = __shfl(acc.x, srcl), py = __shfl(acc.y, srcl), pz = __shfl(acc.z, srcl), pw = __shfl(acc.w, srcl);
+        tot.x += px; tot.y += py; tot.z += pz; tot.w += pw;
+    }
+    if (lane_on && f == 0) {
+        const float inv = 1.0f / (float)T;
+        *reinterpret_cast<float4*>(xbar + ((long long)c * N + n) * V + 4 * g) = make_float4(tot.x * inv, tot.y * inv, tot.z * inv, tot.w * inv);
+    }
 }
 
 // xbar[c][n][v] = mean_t value(n,c,t,v)
@@ -446,6 +578,20 @@ extern "C" int tamgcn_maxpool_bwd(const tamgcn_src* gy, const tamgcn_src* src, c
     TG_CHECK(gy && src && gy->x1 && src->x1 && src_save && d && grid_ok(N, C) && stride >= 1, "tamgcn_maxpool_bwd: bad args");
     const RowGeo geo = row_geo(N, C, T_in * V, false);
     const size_t lds = sizeof(float) * (size_t)(EW_THREADS / geo.tpr) * ((size_t)T_in * V + (size_t)T_out * V);
+    const bool al16 = ((((uintptr_t)gy->x1 | (uintptr_t)(gy->x2 ? gy->x2 : gy->x1) | (uintptr_t)src->x1 | (uintptr_t)d) & 15) == 0);
+    static int vec_env = -1;
+    if (vec_env < 0) { const char* e = getenv("TAMGCN_POOL_VEC"); vec_env = e ? atoi(e) : 1; }     // 0: the staged kernel (A/B)
+    if (vec_env && (V & 3) == 0 && (stride == 1 || stride == 2) && al16 && !src->x2 && T_out == (T_in - 1) / stride + 1) {
+        if (stride == 1)
+            hipLaunchKernelGGL(maxpool_bwd_vec_kernel<1>, row_grid(geo), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                               geo, make_src(*gy), make_src(*src), src_save, C, T_in, T_out, V, d, dctot, dcoff, N, part);
+        else
+            hipLaunchKernelGGL(maxpool_bwd_vec_kernel<2>, row_grid(geo), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                               geo, make_src(*gy), make_src(*src), src_save, C, T_in, T_out, V, d, dctot, dcoff, N, part);
+        tamgcn_note_kernel("maxpool_bwd_vec_kernel<%d>", stride);
+        TG_LAUNCH_CHECK("tamgcn_maxpool_bwd");
+        return 0;
+    }
     if (lds <= 64 * 1024)
         hipLaunchKernelGGL(maxpool_bwd_kernel<1>, row_grid(geo), dim3(EW_THREADS), lds, (hipStream_t)stream,
                            geo, make_src(*gy), make_src(*src), src_save, C, T_in, T_out, V, stride, d, dctot, dcoff, N, part);
@@ -458,8 +604,19 @@ extern "C" int tamgcn_maxpool_bwd(const tamgcn_src* gy, const tamgcn_src* src, c
 }
 
 extern "C" int tamgcn_add_act_fwd(const tamgcn_src* a, const tamgcn_src* res, int relu,
-                                  int N, int C, int T, int V, float* out, float* rowmean, void* stream) {
+                                  int N, int C, int T, int V, float* out, float* rowmean, float* xbar, void* stream) {
     TG_CHECK(a && a->x1 && out && grid_ok(N, C), "tamgcn_add_act_fwd: bad args");
+    if (xbar) {
+        TG_CHECK(!rowmean && (V & 3) == 0 && V <= 64, "tamgcn_add_act_fwd: the frame-mean output needs V %% 4 == 0, V <= 64 and no row-mean output");
+        const bool al16 = (((uintptr_t)a->x1 | (uintptr_t)(a->x2 ? a->x2 : a->x1) | (uintptr_t)out | (uintptr_t)xbar |
+                            (uintptr_t)(res ? res->x1 : a->x1) | (uintptr_t)((res && res->x2) ? res->x2 : a->x1)) & 15) == 0;
+        TG_CHECK(al16, "tamgcn_add_act_fwd: the frame-mean form needs 16-byte aligned operands");
+        hipLaunchKernelGGL(add_act_fwd_tmean_kernel, dim3((unsigned)ceil_div(N * C, EW_THREADS / 16)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                           make_src(*a), res ? make_src(*res) : null_src(), res ? 1 : 0, relu, N, C, T, V, out, xbar);
+        tamgcn_note_kernel("add_act_fwd_tmean_kernel");
+        TG_LAUNCH_CHECK("tamgcn_add_act_fwd");
+        return 0;
+    }
     const RowGeo geo = row_geo(N, C, T * V, true);
     hipLaunchKernelGGL(add_act_fwd_kernel, row_grid(geo), dim3(EW_THREADS), 0, (hipStream_t)stream,
                        geo, make_src(*a), res ? make_src(*res) : null_src(), res ? 1 : 0, relu, C, T * V, out, rowmean);

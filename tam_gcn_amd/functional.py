@@ -282,8 +282,11 @@ def gcn_forward(x, P, training, save):
             d_pre, dpart = ops.conv(xs, K=Cin, w=P.Wd, bias=P.bd, M=Cout, stats=training)
             if ev is not None:
                 coef_d, save_d = ev['d']
-    # pooled joint embeddings (conv1/conv2 commute with the mean over T)
-    xbar = ops.tmean(xs, Cin)                                             # (Cin, N, V)
+    # pooled joint embeddings (conv1/conv2 commute with the mean over T): the previous block's last pass left
+    # them beside its output (ops.add_act_fwd(xbar=True) -> attach_xbar) unless something touched the tensor since
+    xbar = taken_xbar(x, Cin)
+    if xbar is None:
+        xbar = ops.tmean(xs, Cin)                                         # (Cin, N, V)
     pq, _ = ops.conv(S(xbar.view(1, Cin, N, V)), K=Cin, w=P.W12, bias=P.B12, M=S_ * 2 * R)
     pq = pq.view(S_ * 2 * R, N, V)
     # E = alpha*(W4 tanh(p_u - q_v) + b4) + A for every channel, once per layer (N*S*Cout*V*V floats: 1.7 GB over the model at
@@ -417,6 +420,25 @@ class TcnParams:
                  'bn_pool', 'Wl', 'bl', 'bn_l', 'rmode', 'Wr', 'br', 'bnr', 'rk', 'relu')
 
 
+def attach_xbar(out, xb):
+    """Remember the frame means (C, N, V) of `out` ON the tensor object, with the version they belong to."""
+    if xb is not None:
+        out._tamgcn_xbar = (xb, out._version)
+    return out
+
+
+def taken_xbar(x, Cin):
+    """The frame means a producer attached to exactly this tensor object, if it has not been written since."""
+    tag = getattr(x, '_tamgcn_xbar', None)
+    if tag is None:
+        return None
+    xb, ver = tag
+    N, C_, _, V = x.shape
+    if ver != x._version or C_ != Cin or tuple(xb.shape) != (Cin, N, V) or xb.device != x.device:
+        return None
+    return xb
+
+
 def _tpad(k, d):
     return (k + (k - 1) * (d - 1) - 1) // 2
 
@@ -489,7 +511,8 @@ def tcn_forward(g, P, training, save, xres=None, pool=None):
         out, rm = ops.add_act_fwd(S(cat_pre, coef=coef_c), res, P.relu, Cout, rowmean=True)
         pool.append(rm)
     else:
-        out = ops.add_act_fwd(S(cat_pre, coef=coef_c), res, P.relu, Cout)
+        out, xb = ops.add_act_fwd(S(cat_pre, coef=coef_c), res, P.relu, Cout, xbar=True)
+        attach_xbar(out, xb)
     sv = None
     if save:
         sv = dict(g=g, xres=xres, h_pre=h_pre, cat_pre=cat_pre, r_pre=r_pre, out=out, coef_h=coef_h, save_h=save_h,

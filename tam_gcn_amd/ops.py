@@ -632,15 +632,25 @@ def maxpool_bwd(gy, src, src_save, C_, stride, d, dcoff):
     return part
 
 
-def add_act_fwd(a, res, relu, C_, rowmean=False):
-    """rowmean: also return the (N, C) means over (t, v) of the output (the model head's pooling input)."""
+XBAR_FOLD = os.environ.get('TAMGCN_XBAR_FOLD', '1') != '0'    # 0: every block computes its own frame means (tamgcn_tmean)
+
+
+def add_act_fwd(a, res, relu, C_, rowmean=False, xbar=False):
+    """rowmean: also return the (N, C) means over (t, v) of the output (the model head's pooling input).
+    xbar: also return the (C, N, V) means over t of the output (the next block's pooled joint-embedding input) -- or None
+    where the fused form does not apply (V % 4 != 0, V > 64)."""
     N, _, T, V = a.x1.shape
     out = empty(N, C_, T, V, like=a.x1)
     rm = torch.empty(N, C_, device=out.device, dtype=torch.float32) if rowmean else None
+    xb = None
+    if xbar and not rowmean and XBAR_FOLD and V % 4 == 0 and V <= 64:
+        xb = empty(C_, N, V, like=a.x1)
     ac = a.c()
     rc = res.c() if res is not None else None
     _lib.check(_lib_().tamgcn_add_act_fwd(C.byref(ac), C.byref(rc) if rc is not None else None, int(relu),
-                                          N, C_, T, V, _ptr(out), _ptr(rm), _stream()), 'tamgcn_add_act_fwd')
+                                          N, C_, T, V, _ptr(out), _ptr(rm), _ptr(xb), _stream()), 'tamgcn_add_act_fwd')
+    if xbar:
+        return out, xb
     return (out, rm) if rowmean else out
 
 

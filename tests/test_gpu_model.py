@@ -236,6 +236,51 @@ def test_harness_sgd_steps(flat, fix, golden_models):
     assert not bad.any(), [(k, got[i, 1], refd[i, 1], refd64[i, 1]) for i, k in enumerate(sd.keys()) if bad[i]][:5]
 
 
+def test_frame_means_handed_from_block_to_block(golden_models):
+    """Blocks l1..l9 leave the frame means of their output beside it (ops.add_act_fwd(xbar=True)) and the next block's CTRGC
+    takes them instead of launching tamgcn_tmean: same logits and gradients to fp32 rounding as with the hand-over off, one
+    tmean launch left (l1's, on the stem output), and a tensor written in place between two blocks is NOT trusted."""
+    from tam_gcn_amd import ops, functional as Fn
+    dev = torch.device('cuda:0')
+    tag, margs, shape = MODEL_CASES[2]
+    m = M.Model(**margs)
+    fill_state_(m.state_dict(), seed=MODEL_PARAM_SEED)
+    m = m.to(dev).train()
+    x = make_input(shape, seed=MODEL_X_SEED).to(dev)
+    lab = make_labels(shape[0], margs['num_class'], seed=MODEL_LABEL_SEED).to(dev)
+    calls = []
+    orig = ops.tmean
+
+    def spy(*a, **k):
+        calls.append(1)
+        return orig(*a, **k)
+    res = {}
+    try:
+        ops.tmean = spy
+        for fold in (True, False):
+            ops.XBAR_FOLD = fold
+            del calls[:]
+            for p in m.parameters():
+                p.grad = None
+            logits = m(x)
+            torch.nn.functional.cross_entropy(logits, lab).backward()
+            torch.cuda.synchronize()
+            res[fold] = (logits.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()}, len(calls))
+    finally:
+        ops.tmean, ops.XBAR_FOLD = orig, True
+    assert res[True][2] == 1 and res[False][2] == 10
+    assert float((res[True][0] - res[False][0]).abs().max()) <= 1e-5 * float(res[False][0].abs().max())
+    for k, g in res[False][1].items():
+        assert float((res[True][1][k] - g).norm()) <= 2e-3 * float(g.norm()) + 1e-7, k
+    # an in-place write between two blocks invalidates the hand-over
+    out = m.l1(Fn.StemFn.run(m.data_bn, x.unsqueeze(-1) if x.dim() == 4 else x, m.data_bn.weight, m.data_bn.bias) if False else
+               torch.rand(2, 3, 16, 20, device=dev))
+    assert Fn.taken_xbar(out, out.shape[1]) is not None
+    with torch.no_grad():
+        out.mul_(2.0)
+    assert Fn.taken_xbar(out, out.shape[1]) is None
+
+
 def test_frozen_backbone_usage():
     """The cross-modal caller freezes the CTR-GCN and reads extract_feature (reference models/resnet_gcn_attention.py:24-26,
     82-85): frozen parameters get no gradients, a downstream head still trains, and a gradient w.r.t. the input equals the

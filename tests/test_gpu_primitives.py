@@ -632,3 +632,63 @@ def test_de_tail_r16_bit_identical_beside_other_streams_in_a_graph():
         for i, (got, want) in enumerate(zip(outs, ref)):
             for nm, a_, b_ in zip(('dA', 'dW4', 'db4', 'dalpha', 'dpq'), got, want):
                 assert torch.equal(a_, b_), f'replay {rep}, problem {i}: {nm} differs by {float((a_ - b_).abs().max()):.3e}'
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 13, 20, 1), (3, 32, 12, 20, 2), (2, 16, 7, 20, 2), (2, 64, 5, 64, 1), (1, 16, 1, 20, 1), (2, 16, 2, 20, 2)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_maxpool_bwd_vector_kernel(shape):
+    """The LDS-free max-pool gradient (V % 4 == 0): two-source gradient prologue, channel slices of wider tensors, ragged and
+    tiny T, both strides, exact ties between window candidates (zeros behind the ReLU and planted equal positives: aten routes
+    the gradient to the FIRST maximum) -- against autograd in fp64."""
+    from tam_gcn_amd import ops
+    from tam_gcn_amd.ops import S
+    N, C_, T, V, s = shape
+    d = dev()
+    T2 = (T - 1) // s + 1
+    Ch, Cg = C_ + 8, C_ + 4
+    h = rnd((N, Ch, T, V), 1)
+    h[:, :, ::3] = h[:, :, :1].clone()                   # exact ties between frames 0, 3, 6, ... (and their neighbours' windows)
+    ch = torch.stack((1 + 0.3 * rnd((Ch,), 2), torch.zeros(Ch), 0.2 * rnd((Ch,), 3)))
+    g1, g2 = rnd((N, Cg, T2, V), 4), rnd((N, Cg, T2, V), 5)
+    cg = torch.stack((1 + 0.2 * rnd((Cg,), 6), 0.3 * rnd((Cg,), 7), 0.1 * rnd((Cg,), 8)))
+    ap = lambda c, a, b=None: c[0][None, :, None, None] * a + (c[1][None, :, None, None] * b if b is not None else 0) + c[2][None, :, None, None]
+    hb = ap(ch.double(), h.double())[:, 8:].clone().requires_grad_(True)
+    gv = ap(cg.double(), g1.double(), g2.double())[:, 4:]
+    (F.max_pool2d(torch.relu(hb), (3, 1), (s, 1), (1, 0)) * gv).sum().backward()
+    mu = 0.1 * rnd((2, Ch), 9)
+    dd = torch.full((N, Ch, T, V), 5.0, device=d)
+    t = lambda z: z.to(d)
+    bp = ops.maxpool_bwd(S(t(g1), t(g2), t(cg), coff=4), S(t(h), None, t(ch), coff=8, act=1), t(mu), C_, s, dd, 8)
+    torch.cuda.synchronize()
+    assert 'vec' in ops._lib_().tamgcn_last_kernel().decode()
+    got = dd[:, 8:].double().cpu()
+    assert float((got - hb.grad).abs().max()) <= 2e-6 * (float(hb.grad.abs().max()) + 1e-6)
+    assert float((dd[:, :8] - 5).abs().max()) == 0
+    hc = (h.double() - mu[0].double()[None, :, None, None])[:, 8:]
+    sums = bp.double().sum(2).cpu()[:, 8:]
+    cnt = N * T * V
+    assert float((sums[0] - hb.grad.sum((0, 2, 3))).abs().max()) <= 2e-6 * cnt
+    assert float((sums[1] - (hb.grad * hc).sum((0, 2, 3))).abs().max()) <= 4e-6 * cnt
+
+
+@pytest.mark.parametrize('shape', [(3, 24, 13, 20), (2, 16, 64, 20), (2, 8, 9, 64), (1, 5, 1, 20), (2, 6, 7, 12)], ids=lambda s: 'x'.join(map(str, s)))
+def test_add_act_fwd_emits_the_next_blocks_frame_means(shape):
+    """tamgcn_add_act_fwd with the xbar output: out = relu(bn(a) + bn(res)) and the (C, N, V) means over t of out in one pass,
+    against torch; the means must equal tamgcn_tmean of the written tensor to fp32 rounding (they replace it)."""
+    from tam_gcn_amd import ops
+    from tam_gcn_amd.ops import S
+    N, C_, T, V = shape
+    d = dev()
+    a, r = rnd((N, C_ + 3, T, V), 1), rnd((N, C_, T, V), 2)
+    ca, cr = rnd((3, C_ + 3), 3), rnd((3, C_), 4)
+    ap = lambda c, x: c[0][None, :, None, None] * x + c[2][None, :, None, None]
+    ref = torch.relu(ap(ca.double(), a.double())[:, 3:] + ap(cr.double(), r.double()))
+    t = lambda z: z.to(d)
+    out, xb = ops.add_act_fwd(S(t(a), None, t(ca), coff=3), S(t(r), None, t(cr)), True, C_, xbar=True)
+    assert xb is not None and tuple(xb.shape) == (C_, N, V)
+    assert float((out.double().cpu() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    want = ref.mean(2).permute(1, 0, 2)
+    assert float((xb.double().cpu() - want).abs().max()) <= 2e-6 * float(want.abs().max())
+    close(xb, ops.tmean(S(out), C_), 1e-5, 1e-6, 'against tamgcn_tmean')
+    out2 = ops.add_act_fwd(S(t(a), None, t(ca), coff=3), S(t(r), None, t(cr)), True, C_)
+    assert torch.equal(out2, out)                                      # the same values as the plain pass
