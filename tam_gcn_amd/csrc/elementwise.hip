@@ -446,12 +446,14 @@ __global__ __launch_bounds__(EW_THREADS) void apply_kernel(RowGeo geo, SrcDev sr
 
 // out = act(a + res) AND xbar[c][n][v] = mean_t out(n,c,t,v), the next block's pooled joint embedding input (reference
 // models/ctrgcn.py:172-174: conv1 / conv2 commute with the mean over T), in the pass that writes `out`: V % 4 == 0, V <= 64.
-// 16 lanes per (n, c) row; lane l = f * V4 + g owns the 16-byte joint group g of the frames f, f + F, f + 2F, ... (F = 16 / V4
-// whole frames per step of the group: 240 contiguous bytes at V = 20), so its partial sum is ONE float4 and the sum over the F
-// frame phases is a fixed-order chain of shuffles: deterministic, graph replay = eager bit for bit.
+// One wave per (n, c) row, as four 16-lane groups; lane (sub, l = f * V4 + g) owns the 16-byte joint group g of the frames
+// f + F * (sub + 4k) (F = 16 / V4 whole frames per step of a group: 240 contiguous bytes at V = 20), so its partial sum is ONE
+// float4; the sums over the F frame phases and then over the four groups are fixed-order shuffle chains: deterministic, graph
+// replay = eager bit for bit.
 __global__ __launch_bounds__(EW_THREADS) void add_act_fwd_tmean_kernel(SrcDev a, SrcDev res, int has_res, int relu, int N, int C, int T, int V,
                                                                        float* out, float* xbar) {
-    const int row = blockIdx.x * (EW_THREADS / 16) + (threadIdx.x >> 4), l = threadIdx.x & 15;
+    const int row = blockIdx.x * (EW_THREADS / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int sub = lane >> 4, l = lane & 15;
     const int V4 = V >> 2, F = 16 / V4;
     const bool rowok = row < N * C;
     const int r = rowok ? row : 0;
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(EW_THREADS) void add_act_fwd_tmean_kernel(SrcDev a,
     float* op = out + ((long long)n * C + c) * L;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (lane_on) {
-        for (int t = f; t < T; t += F) {
+        for (int t = f + F * sub; t < T; t += 4 * F) {
             const int i4 = t * V4 + g;
             float4 v = row_val4(ra, i4);
             if (has_res) { const float4 q = row_val4(rr, i4); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
@@ -474,14 +476,17 @@ __global__ __launch_bounds__(EW_THREADS) void add_act_fwd_tmean_kernel(SrcDev a,
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
     }
-    // frame phases 1 .. F-1 into phase 0, in order (every lane of the wave takes part in the shuffles)
+    // frame phases 1 .. F-1 into phase 0, in order, inside every 16-lane group (all lanes of the wave take part in the shuffles)
     float4 tot = acc;
     for (int ff = 1; ff < F; ++ff) {
-        const int srcl = (threadIdx.x & 48) + ff * V4 + g;           // same 16-lane group (lane & 48 = its base inside the wave)
+        const int srcl = (lane & 48) + ff * V4 + g;
         const float px = __shfl(acc.x, srcl), py = __shfl(acc.y, srcl), pz = __shfl(acc.z, srcl), pw = __shfl(acc.w, srcl);
         tot.x += px; tot.y += py; tot.z += pz; tot.w += pw;
     }
-    if (lane_on && f == 0) {
+    // ... then the four groups: (0 + 1) + (2 + 3)
+    tot.x += __shfl_xor(tot.x, 16); tot.y += __shfl_xor(tot.y, 16); tot.z += __shfl_xor(tot.z, 16); tot.w += __shfl_xor(tot.w, 16);
+    tot.x += __shfl_xor(tot.x, 32); tot.y += __shfl_xor(tot.y, 32); tot.z += __shfl_xor(tot.z, 32); tot.w += __shfl_xor(tot.w, 32);
+    if (lane_on && f == 0 && sub == 0) {
         const float inv = 1.0f / (float)T;
         *reinterpret_cast<float4*>(xbar + ((long long)c * N + n) * V + 4 * g) = make_float4(tot.x * inv, tot.y * inv, tot.z * inv, tot.w * inv);
     }
@@ -611,7 +616,7 @@ extern "C" int tamgcn_add_act_fwd(const tamgcn_src* a, const tamgcn_src* res, in
         const bool al16 = (((uintptr_t)a->x1 | (uintptr_t)(a->x2 ? a->x2 : a->x1) | (uintptr_t)out | (uintptr_t)xbar |
                             (uintptr_t)(res ? res->x1 : a->x1) | (uintptr_t)((res && res->x2) ? res->x2 : a->x1)) & 15) == 0;
         TG_CHECK(al16, "tamgcn_add_act_fwd: the frame-mean form needs 16-byte aligned operands");
-        hipLaunchKernelGGL(add_act_fwd_tmean_kernel, dim3((unsigned)ceil_div(N * C, EW_THREADS / 16)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(add_act_fwd_tmean_kernel, dim3((unsigned)ceil_div(N * C, EW_THREADS / 64)), dim3(EW_THREADS), 0, (hipStream_t)stream,
                            make_src(*a), res ? make_src(*res) : null_src(), res ? 1 : 0, relu, N, C, T, V, out, xbar);
         tamgcn_note_kernel("add_act_fwd_tmean_kernel");
         TG_LAUNCH_CHECK("tamgcn_add_act_fwd");
