@@ -321,6 +321,14 @@ int tamgcn_tconv_supported(int V, int Cb, int KT, int nb, const int* dil, int st
 int tamgcn_tconv_nparts(const tamgcn_tconv_desc* d, int backward);
 int tamgcn_tconv_fwd(const tamgcn_tconv_desc* d, void* stream);
 int tamgcn_tconv_bwd(const tamgcn_tconv_desc* d, void* stream);
+/* Weight gradient of every temporal branch in one launch (aten::convolution_backward, weight part):
+ *   dW_b[m][k][tap] = sum_{n,t,v} gy(n, src.coff + b*Cb + m, t, v) * act(mask)(n, mask.coff + b*Cb + k, t*stride + tap*dil_b - pad_b, v)
+ * d->src = the gradient w.r.t. the branches' outputs (two-source prologue, T_out frames), d->mask = the forward's source with
+ * its prologue (T_in frames).  The contraction is split over (sample, frame tile) items into nsplit = d->yctot partial slabs
+ * d->y = part [nsplit][nb][Cb][Cb][KT] (deterministic: no float atomics; reduce with tamgcn_reduce_*);
+ * 1 <= nsplit <= tamgcn_tconv_wgrad_max_split(d).  Shapes: as tamgcn_tconv_supported(). */
+int tamgcn_tconv_wgrad_max_split(const tamgcn_tconv_desc* d);
+int tamgcn_tconv_wgrad(const tamgcn_tconv_desc* d, void* stream);
 
 /* MaxPool2d((3,1), stride (s,1), pad (1,0)) over the prologue value (models/ctrgcn.py:117),
  * written at channel ycoff of y (N, yctot, T_out, V) + (sum, sum^2) partials [2][yctot][nparts]. */

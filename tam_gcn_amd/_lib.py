@@ -143,6 +143,8 @@ SIGNATURES = {
     'tamgcn_tconv_nparts': (_i, [C.POINTER(TconvDesc), _i]),
     'tamgcn_tconv_fwd': (_i, [C.POINTER(TconvDesc), _p]),
     'tamgcn_tconv_bwd': (_i, [C.POINTER(TconvDesc), _p]),
+    'tamgcn_tconv_wgrad_max_split': (_i, [C.POINTER(TconvDesc)]),
+    'tamgcn_tconv_wgrad': (_i, [C.POINTER(TconvDesc), _p]),
     'tamgcn_maxpool_fwd': (_i, [_SP, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _p]),
     'tamgcn_maxpool_post_fwd': (_i, [_SP, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _p, _i, _p]),
     'tamgcn_maxpool_bwd': (_i, [_SP, _SP, _p, _i, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p]),

@@ -542,16 +542,16 @@ extern "C" int tamgcn_tconv_nparts(const tamgcn_tconv_desc* d, int backward) {
     return d->N * p.ngrp * p.nsl;
 }
 
-static int tc_common_checks(const tamgcn_tconv_desc* d, const char* who) {
+static int tc_common_checks(const tamgcn_tconv_desc* d, const char* who, bool need_w = true) {
     TG_CHECK(d && d->src.x1 && d->y, "%s: null pointer", who);
     TG_CHECK(d->N > 0 && d->N <= (1 << 20) && d->T_in > 0 && d->V > 0 && d->Cb > 0 && d->nb >= 1 && d->nb <= TC_MAXB && d->stride >= 1 && d->stride <= 2,
              "%s: bad dims N=%d T_in=%d V=%d Cb=%d nb=%d stride=%d", who, d->N, d->T_in, d->V, d->Cb, d->nb, d->stride);
     for (int b = 0; b < d->nb; ++b) {
-        TG_CHECK(d->w[b], "%s: branch %d has no weights", who, b);
+        TG_CHECK(!need_w || d->w[b], "%s: branch %d has no weights", who, b);
         TG_CHECK(d->dil[b] >= 1 && ((d->KT - 1) * d->dil[b]) % 2 == 0, "%s: branch %d: (KT-1)*dil must be even (symmetric padding)", who, b);
         TG_CHECK(((uintptr_t)d->w[b] & 3) == 0, "%s: unaligned weights", who);
     }
-    TG_CHECK((long long)d->src.ctot * d->T_in * d->V < (1LL << 31) && (long long)d->yctot * d->T_in * d->V < (1LL << 31),
+    TG_CHECK((long long)d->src.ctot * d->T_in * d->V < (1LL << 31) && (!need_w || (long long)d->yctot * d->T_in * d->V < (1LL << 31)),
              "%s: a sample exceeds 2^31 elements", who);
     return 0;
 }
@@ -631,4 +631,285 @@ extern "C" int tamgcn_tconv_bwd(const tamgcn_tconv_desc* d, void* stream) {
     if (tc_launch<true>(a, p, d->KT, grid, (hipStream_t)stream)) return -1;
     TG_LAUNCH_CHECK("tamgcn_tconv_bwd");
     return 0;
+}
+
+// ===========================================================================
+// Weight gradient of the temporal branches (aten::convolution_backward's weight part for every branch's k x 1 convolution,
+// reference models/ctrgcn.py:52-69 as used at :101-111):
+//   dW_b[m][k][tap] = sum_{n,t,v} gy(n, b*Cb + m, t, v) * act(src)(n, b*Cb + k, t*stride + tap*dil_b - pad_b, v)
+// for all branches in ONE launch.  The contraction runs over the columns p = (n, t, v): a workgroup owns a 16- or 32-channel
+// block of k, a 16- or 32-channel block of m (64-channel branches: four such blocks) and every tap, loops over its share of
+// the (sample, frame tile) items and keeps the KTL x MTL x KT accumulator tiles in registers; per item it stages
+//   Xs  the activated source rows of its k block with their temporal halo -- the forward's line buffer [k][slot][Vp], so a
+//       strided forward and the taps are LDS offsets -- and
+//   Gs  the gradient rows of its m block, two-source BatchNorm-backward prologue applied, [m][column],
+// and issues, per group of four columns, MFMAs  D[k][m] += X[k][4 cols + tap shift] . G[4 cols][m]  (v_mfma_f32_16x16x4_f32:
+// exact fp32).  Row pitches == 2 (mod 32): the 16 rows x 2 columns a 32-lane half reads hit 32 banks.  The four waves split
+// the column groups; their tiles meet in LDS once, at the end, and leave as one partial slab per workgroup (reduced in fp64
+// by tamgcn_reduce_*: deterministic, no atomics).
+// Replaces wgrad_kernel<5, ...> (register-staged, p-split), the tap-window form of wgrad_glds_kernel and the scalar stride-2
+// path for these shapes (profiles/r03_roofline_table_nucla.txt: 21-35 % of their roofs).
+// ===========================================================================
+namespace {
+
+constexpr int TW_NT = 256;
+
+struct TwArgs {
+    SrcDev gy, src;                 // gy (N, gy.ctot, T_out, V): branch b = channels gy.coff + b*Cb; src (N, src.ctot, T_in, V) likewise
+    int N, T_in, T_out, V, Cb, nb, stride;
+    int dil[TC_MAXB], pad[TC_MAXB];
+    float* part;                    // [nsplit][nb][Cb][Cb][KT]
+    int nsplit, nblk;               // nblk: (k block, m block) pairs per branch
+    int BT, TIN, LB, PX, PG, Vs, Vp, nsl, ntt;
+};
+
+template <int KTL, int MTL, int KT>
+__global__ __launch_bounds__(TW_NT, 2) void tconv_wgrad_kernel(const TwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float tw_smem[];
+    const int PX = a.PX, PG = a.PG;
+    float* Xs = tw_smem;                                   // [KTL*16][PX]
+    float* Gs = Xs + KTL * 16 * PX;                        // [MTL*16][PG]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kq = lane >> 4;
+    const int sp = blockIdx.x;                             // split: items sp, sp + nsplit, ...
+    const int br = blockIdx.y / a.nblk, blk = blockIdx.y - br * a.nblk;
+    const int nmb = a.Cb / (MTL * 16);                     // m blocks per branch
+    const int kb = blk / nmb, mb = blk - kb * nmb;
+    const int k0 = kb * KTL * 16, m0 = mb * MTL * 16;
+    const int V = a.V, Vs = a.Vs, Vp = a.Vp;
+    const float rVs = 1.0f / (float)Vs, rVp = 1.0f / (float)Vp;
+    const int dil = a.dil[br], padb = a.pad[br];
+    const long long cs = (long long)a.T_in * V, gcs = (long long)a.T_out * V;
+    const int pk = tid >> 4, psub = tid & 15;
+    const int LB4 = a.LB >> 2;
+
+    f32x4 acc[KTL][MTL][KT];
+#pragma unroll
+    for (int kt = 0; kt < KTL; ++kt)
+#pragma unroll
+        for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+            for (int tp = 0; tp < KT; ++tp) acc[kt][mt][tp] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nitems = a.N * a.ntt * a.nsl;
+    for (int item = sp; item < nitems; item += a.nsplit) {
+        const int n = item / (a.ntt * a.nsl), rem = item - n * (a.ntt * a.nsl);
+        const int tti = rem / a.nsl, sl = rem - tti * a.nsl;
+        const int v0 = sl * Vs;
+        const int t0 = tti * a.BT;
+        const int bt = min(a.BT, a.T_out - t0);
+        const int ncols = bt * Vs;
+        const int tin0 = t0 * a.stride - padb;
+        const bool flatg = a.nsl == 1;
+        __syncthreads();                                   // the previous item's MFMAs are done with Xs / Gs
+        // ---- stage the source rows (prologue + ReLU, zero padding), thread (row pk [+16], pieces psub + 16*i).  All loads of a
+        // row block are requested before the first is used (unconditional: a piece outside the source re-reads the row's start)
+#pragma unroll
+        for (int kt = 0; kt < KTL; ++kt) {
+            const int sch = a.src.coff + br * a.Cb + k0 + kt * 16 + pk;
+            const float c1 = a.src.coef ? a.src.coef[sch] : 1.f, c0 = a.src.coef ? a.src.coef[2 * a.src.ctot + sch] : 0.f;
+            const float* xrow = a.src.x1 + ((long long)n * a.src.ctot + sch) * cs;
+            float* xs = Xs + (kt * 16 + pk) * PX;
+            float4 xr[TC_NPF];
+            unsigned okm = 0;
+#pragma unroll
+            for (int i = 0; i < TC_NPF; ++i) {
+                const int pos = (psub + 16 * i) << 2;
+                const int slot = tc_div(pos, rVp), v = pos - slot * Vp;
+                const int th = tin0 + slot;
+                const bool ok = psub + 16 * i < LB4 && th >= 0 && th < a.T_in;
+                if (ok) okm |= 1u << i;
+                xr[i] = *reinterpret_cast<const float4*>(xrow + (ok ? th * V + v0 + v : 0));
+            }
+#pragma unroll
+            for (int i = 0; i < TC_NPF; ++i) {
+                if (psub + 16 * i < LB4) {
+                    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (okm & (1u << i)) {
+                        o.x = fmaf(c1, xr[i].x, c0); o.y = fmaf(c1, xr[i].y, c0); o.z = fmaf(c1, xr[i].z, c0); o.w = fmaf(c1, xr[i].w, c0);
+                        if (a.src.act == 1) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+                    }
+                    const int pos = (psub + 16 * i) << 2;
+                    *reinterpret_cast<float2*>(xs + pos) = make_float2(o.x, o.y);     // rows are 8-byte aligned (pitch == 2 mod 32)
+                    *reinterpret_cast<float2*>(xs + pos + 2) = make_float2(o.z, o.w);
+                }
+            }
+        }
+        // ---- stage the gradient rows (linear two-source prologue), [m][column]; columns >= ncols are zero
+        const int NG4 = (PG - 2) >> 2;
+        const float* g2p = a.gy.x2 ? a.gy.x2 : a.gy.x1;
+#pragma unroll
+        for (int mt = 0; mt < MTL; ++mt) {
+            const int gch = a.gy.coff + br * a.Cb + m0 + mt * 16 + pk;
+            const float c1 = a.gy.coef ? a.gy.coef[gch] : 1.f, c2 = (a.gy.coef && a.gy.x2) ? a.gy.coef[a.gy.ctot + gch] : 0.f,
+                        c0 = a.gy.coef ? a.gy.coef[2 * a.gy.ctot + gch] : 0.f;
+            const long long gb = ((long long)n * a.gy.ctot + gch) * gcs;
+            float* gs = Gs + (mt * 16 + pk) * PG;
+            float4 g1[4], g2[4];
+            int goff[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                  // NG4 <= 64 (host)
+                const int col = (psub + 16 * i) << 2;
+                const bool full = col + 4 <= ncols;
+                const int cc = full ? col : 0;
+                const int fr = tc_div(cc, rVs), v = cc - fr * Vs;
+                goff[i] = flatg ? t0 * V + cc : (t0 + fr) * V + v0 + v;
+                g1[i] = *reinterpret_cast<const float4*>(a.gy.x1 + gb + goff[i]);
+                g2[i] = *reinterpret_cast<const float4*>(g2p + gb + goff[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c4 = psub + 16 * i, col = c4 << 2;
+                if (c4 < NG4) {
+                    float o[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (col + 4 <= ncols) {
+                        o[0] = fmaf(c1, g1[i].x, fmaf(c2, g2[i].x, c0)); o[1] = fmaf(c1, g1[i].y, fmaf(c2, g2[i].y, c0));
+                        o[2] = fmaf(c1, g1[i].z, fmaf(c2, g2[i].z, c0)); o[3] = fmaf(c1, g1[i].w, fmaf(c2, g2[i].w, c0));
+                    } else if (col < ncols) {              // the tile's last, partial group (V % 4 != 0): element-wise
+                        const int fr = tc_div(col, rVs), v = col - fr * Vs;
+                        const long long off = flatg ? (long long)t0 * V + col : (long long)(t0 + fr) * V + v0 + v;
+                        for (int r = 0; r < 4 && col + r < ncols; ++r)
+                            o[r] = fmaf(c1, a.gy.x1[gb + off + r], fmaf(c2, g2p[gb + off + r], c0));
+                    }
+                    *reinterpret_cast<float2*>(gs + col) = make_float2(o[0], o[1]);
+                    *reinterpret_cast<float2*>(gs + col + 2) = make_float2(o[2], o[3]);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- MFMAs: this wave's groups of four columns
+        const int ngrp = (ncols + 3) >> 2;
+        for (int g = wave; g < ngrp; g += 4) {
+            const int col = 4 * g + kq;                    // this lane's contraction column (a column >= ncols has a zero in Gs)
+            const int cc = col < ncols ? col : 0;
+            const int fr = tc_div(cc, rVs);
+            const int boff = fr * a.stride * Vp + (cc - fr * Vs);
+            float bv[MTL];
+#pragma unroll
+            for (int mt = 0; mt < MTL; ++mt) bv[mt] = Gs[(mt * 16 + j) * PG + col];
+#pragma unroll
+            for (int tp = 0; tp < KT; ++tp) {
+                float av[KTL];
+#pragma unroll
+                for (int kt = 0; kt < KTL; ++kt) av[kt] = Xs[(kt * 16 + j) * PX + boff + tp * dil * Vp];
+#pragma unroll
+                for (int kt = 0; kt < KTL; ++kt)
+#pragma unroll
+                    for (int mt = 0; mt < MTL; ++mt) acc[kt][mt][tp] = mfma16(av[kt], bv[mt], acc[kt][mt][tp]);
+            }
+        }
+    }
+    // ---- the four waves' tiles meet in LDS (two waves at a time: the tile set of 32 x 32 x 5 is 20 KB per wave), then leave as
+    // this workgroup's slab: lane (j, kq) holds dW[m = m0 + mt*16 + j][k = k0 + kt*16 + 4*kq + r][tap]
+    __syncthreads();
+    float* Rs = tw_smem;                                   // [2][KTL*MTL*KT*256]
+    constexpr int NTILE = KTL * MTL * KT;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if ((wave >> 1) == pass) {
+            float* rs = Rs + (wave & 1) * NTILE * 256;
+            int ti = 0;
+#pragma unroll
+            for (int kt = 0; kt < KTL; ++kt)
+#pragma unroll
+                for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+                    for (int tp = 0; tp < KT; ++tp, ++ti)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float* q = rs + ti * 256 + r * 64 + lane;
+                            *q = pass == 0 ? acc[kt][mt][tp][r] : *q + acc[kt][mt][tp][r];
+                        }
+        }
+        __syncthreads();
+    }
+    float* slab = a.part + (((long long)sp * a.nb + br) * a.Cb) * a.Cb * KT;
+    for (int e = tid; e < NTILE * 256; e += TW_NT) {
+        const int ti = e >> 8, r = (e >> 6) & 3, ln = e & 63;
+        const int tp = ti % KT, mt = (ti / KT) % MTL, kt = ti / (KT * MTL);
+        const int m = m0 + mt * 16 + (ln & 15), k = k0 + kt * 16 + 4 * (ln >> 4) + r;
+        slab[((long long)m * a.Cb + k) * KT + tp] = Rs[e] + Rs[NTILE * 256 + e];
+    }
+}
+
+struct TwPlan { int BT, TIN, LB, PX, PG, Vs, Vp, nsl, ntt, ktl, mtl, nblk; size_t lds; };
+
+static int tw_plan(int V, int Cb, int KT, int span, int stride, int T_out, TwPlan* p) {
+    if (V < 1 || (Cb != 16 && Cb % 32 != 0) || (KT != 3 && KT != 5) || T_out < 1) return -1;
+    p->Vs = V; p->nsl = 1;
+    if (V > 32) { if (V % 16) return -1; p->Vs = 16; p->nsl = V / 16; }
+    p->Vp = (p->Vs + 3) & ~3;
+    p->ktl = p->mtl = Cb == 16 ? 1 : 2;
+    p->nblk = (Cb / (16 * p->ktl)) * (Cb / (16 * p->mtl));
+    // tiles of <= 160 columns whose line buffer stays within 320 floats (two workgroups per CU at 32 channels); shapes whose
+    // halo would leave fewer than six frames (stride 2, V = 25) take 512-float line buffers instead
+    for (int cap = 320; ; cap = 512) {
+        int BT = 160 / p->Vs;
+        if (BT < 1) BT = 1;
+        if (BT > T_out) BT = T_out;
+        for (; BT >= 1; --BT) {
+            p->TIN = (BT - 1) * stride + span + 1;
+            p->LB = p->TIN * p->Vp;
+            if (p->LB <= cap) break;
+        }
+        if (BT >= 1 && (BT >= 6 || BT == T_out || cap == 512)) { p->BT = BT; break; }
+        if (cap == 512) return -1;
+    }
+    const int ncmax = p->BT * p->Vs;
+    p->PX = ((p->LB + 31) & ~31) + 2;                        // == 2 (mod 32)
+    p->PG = ((((ncmax + 3) & ~3) + 31) & ~31) + 2;
+    if ((p->PG - 2) / 4 > 64) return -1;
+    p->ntt = ceil_div(T_out, p->BT);
+    const size_t stage = sizeof(float) * ((size_t)p->ktl * 16 * p->PX + (size_t)p->mtl * 16 * p->PG);
+    const size_t red = sizeof(float) * 2 * (size_t)p->ktl * p->mtl * KT * 256;
+    p->lds = stage > red ? stage : red;
+    return p->lds <= 160 * 1024 ? 0 : -1;
+}
+
+}  // namespace
+
+/* partial slabs tamgcn_tconv_wgrad writes: choose nsplit <= this, size `part` [nsplit][nb][Cb][Cb][KT] */
+extern "C" int tamgcn_tconv_wgrad_max_split(const tamgcn_tconv_desc* d) {
+    TwPlan p;
+    if (!d || d->nb < 1 || d->nb > TC_MAXB) return -1;
+    const int T_out = (d->T_in - 1) / d->stride + 1;
+    if (tw_plan(d->V, d->Cb, d->KT, tc_span(d->dil, d->nb, d->KT), d->stride, T_out, &p)) return -1;
+    return d->N * p.ntt * p.nsl;
+}
+
+/* d->src = the gradient w.r.t. the branches' outputs (two-source prologue, T_out frames), d->mask = the forward's source with its
+ * prologue (T_in frames); d->y = part [nsplit][nb][Cb][Cb][KT], d->yctot = nsplit.  Everything else as tamgcn_tconv_bwd. */
+extern "C" int tamgcn_tconv_wgrad(const tamgcn_tconv_desc* d, void* stream) {
+    if (tc_common_checks(d, "tamgcn_tconv_wgrad", false)) return -1;
+    TG_CHECK((long long)d->mask->ctot * d->T_in * d->V < (1LL << 31), "tamgcn_tconv_wgrad: a sample exceeds 2^31 elements");
+    TG_CHECK(d->mask && d->mask->x1 && !d->mask->x2, "tamgcn_tconv_wgrad: needs the forward source (single-source prologue) in `mask`");
+    TG_CHECK(d->src.coff + d->nb * d->Cb <= d->src.ctot && d->mask->coff + d->nb * d->Cb <= d->mask->ctot, "tamgcn_tconv_wgrad: channel slice out of range");
+    const int T_out = (d->T_in - 1) / d->stride + 1;
+    TG_CHECK(d->T_out == T_out, "tamgcn_tconv_wgrad: T_out=%d inconsistent with T_in=%d stride=%d", d->T_out, d->T_in, d->stride);
+    TwPlan p;
+    TG_CHECK(tw_plan(d->V, d->Cb, d->KT, tc_span(d->dil, d->nb, d->KT), d->stride, T_out, &p) == 0,
+             "tamgcn_tconv_wgrad: no tiling for V=%d Cb=%d KT=%d stride=%d", d->V, d->Cb, d->KT, d->stride);
+    const int nsplit = d->yctot;
+    TG_CHECK(nsplit >= 1 && nsplit <= d->N * p.ntt * p.nsl, "tamgcn_tconv_wgrad: nsplit %d outside 1..%d", nsplit, d->N * p.ntt * p.nsl);
+    const bool al = ((((uintptr_t)d->src.x1 | (uintptr_t)(d->src.x2 ? d->src.x2 : d->src.x1) | (uintptr_t)d->mask->x1) & 3) == 0);
+    TG_CHECK(al, "tamgcn_tconv_wgrad: unaligned operands");
+    TwArgs a;
+    a.gy = make_src(d->src); a.src = make_src(*d->mask);
+    a.N = d->N; a.T_in = d->T_in; a.T_out = T_out; a.V = d->V; a.Cb = d->Cb; a.nb = d->nb; a.stride = d->stride;
+    for (int b = 0; b < TC_MAXB; ++b) { a.dil[b] = b < d->nb ? d->dil[b] : 1; a.pad[b] = (d->KT - 1) * a.dil[b] / 2; }
+    a.part = d->y; a.nsplit = nsplit; a.nblk = p.nblk;
+    a.BT = p.BT; a.TIN = p.TIN; a.LB = p.LB; a.PX = p.PX; a.PG = p.PG; a.Vs = p.Vs; a.Vp = p.Vp; a.nsl = p.nsl; a.ntt = p.ntt;
+    dim3 grid((unsigned)nsplit, (unsigned)(d->nb * p.nblk));
+#define TW_CASE(KTL_, MTL_, KT_)                                                                                        \
+    if (p.ktl == KTL_ && p.mtl == MTL_ && d->KT == KT_) {                                                               \
+        static tg_devmask done = 0;                                                                                     \
+        tg_allow_lds((const void*)tconv_wgrad_kernel<KTL_, MTL_, KT_>, 160 * 1024, &done);                              \
+        hipLaunchKernelGGL((tconv_wgrad_kernel<KTL_, MTL_, KT_>), grid, dim3(TW_NT), p.lds, (hipStream_t)stream, a);    \
+        tamgcn_note_kernel("tconv_wgrad_kernel<%d, %d, %d>", KTL_, MTL_, KT_);                                          \
+        TG_LAUNCH_CHECK("tamgcn_tconv_wgrad");                                                                          \
+        return 0;                                                                                                       \
+    }
+    TW_CASE(1, 1, 5) TW_CASE(2, 2, 5) TW_CASE(1, 1, 3) TW_CASE(2, 2, 3)
+#undef TW_CASE
+    tamgcn_set_error("tamgcn_tconv_wgrad: no instantiation");
+    return -1;
 }

@@ -511,8 +511,13 @@ def tcn_forward(g, P, training, save, xres=None, pool=None):
         out, rm = ops.add_act_fwd(S(cat_pre, coef=coef_c), res, P.relu, Cout, rowmean=True)
         pool.append(rm)
     else:
-        out, xb = ops.add_act_fwd(S(cat_pre, coef=coef_c), res, P.relu, Cout, xbar=True)
-        attach_xbar(out, xb)
+        # the next block's frame means ride along in train mode / under autograd (the step this path is built for); a plain
+        # eval forward keeps tamgcn_tmean, so that it stays bit-compatible with the launch-fused eval path (EVAL_FUSED)
+        if training or save:
+            out, xb = ops.add_act_fwd(S(cat_pre, coef=coef_c), res, P.relu, Cout, xbar=True)
+            attach_xbar(out, xb)
+        else:
+            out = ops.add_act_fwd(S(cat_pre, coef=coef_c), res, P.relu, Cout)
     sv = None
     if save:
         sv = dict(g=g, xres=xres, h_pre=h_pre, cat_pre=cat_pre, r_pre=r_pre, out=out, coef_h=coef_h, save_h=save_h,
@@ -617,6 +622,7 @@ def _tcn_backward(P, sv, dout, need_dg=True, need_dxres=True):
     marks = []
     bi = ops.BNBatch()                                 # the entry norms' backward: one launch once every dh slice is written
     fused = ops.tconv_supported(V, Cb, P.ks, P.dils, s, T)
+    fused_w = fused and ops.tconv_wgrad_pays(V, Cb, s)
     if fused:                                          # every temporal branch's data gradient in ONE launch (csrc/tconv.hip)
         hp_all = ops.tconv_bwd(gcat(0), Cb, P.ks[0], P.dils, s, P.Wt, S(h_pre, coef=sv['coef_h']), sv['save_h'], dh, 0)
     for b in range(nb):
@@ -635,9 +641,13 @@ def _tcn_backward(P, sv, dout, need_dg=True, need_dxres=True):
             marks.append(fk.mark(b))                   # dh slice and moments of branch b done (its wgrad is not awaited)
         G['bn_in'].append((dgam, dbet))
         dbin.append(dbias)
-        with fk.on(b):
-            G['Wt'].append(ops.wgrad(gcat(b * Cb), S(h_pre, coef=sv['coef_h'], coff=b * Cb, act=RELU), M=Cb, K=Cb,
-                                     KT=k, dil=d, stride=s, pad=pad))
+        if not fused_w:
+            with fk.on(b):
+                G['Wt'].append(ops.wgrad(gcat(b * Cb), S(h_pre, coef=sv['coef_h'], coff=b * Cb, act=RELU), M=Cb, K=Cb,
+                                         KT=k, dil=d, stride=s, pad=pad))
+    if fused_w:                                        # every branch's weight gradient in ONE launch, beside the main chain
+        with fk.on(0):
+            G['Wt'] = ops.tconv_wgrad(gcat(0), S(h_pre, coef=sv['coef_h'], act=RELU), Cb, P.ks[0], P.dils, s)
     hp = ops.maxpool_bwd(gcat(nb * Cb), S(h_pre, coef=sv['coef_h'], coff=nb * Cb, act=RELU), sv['save_h'], Cb, s, dh,
                          nb * Cb)
     dgam, dbet, dbias = P.bn_in[nb].bwd(hp, nb * Cb, cnt1, sv['save_h'], nb * Cb, training, coefb_h, nb * Cb, True, batch=bi)

@@ -223,6 +223,46 @@ def tconv_bwd(gy, Cb, KT, dils, stride, ws, mask, center, dh, dcoff=0):
     return part
 
 
+def tconv_wgrad_pays(V, Cb, stride):
+    """Where the one-launch weight gradient of the temporal branches beats the per-branch launches (tools/tconv_bench.py,
+    profiles/r04_tconv_bench.txt, 256 clips): 64-channel branches (129 vs 152 us, strided 176 vs 211), V = 25 except the
+    16-channel stride-1 branches (0.9-1.35 ms vs 1.6-2.6 ms), V = 64 (1.30 vs 1.83 ms); at 16 / 32 channels and V = 20 the two
+    are level (69 vs 74, 104 vs 104, 132 vs 126 us) and the per-branch launches stay."""
+    if V > 32:
+        return True
+    if V % 4:
+        return Cb >= 32 or stride > 1
+    return Cb >= 64
+
+
+def tconv_wgrad(gy, src, Cb, KT, dils, stride):
+    """Weight gradients of every temporal branch in one launch: [dW_b (Cb, Cb, KT, 1) for b in branches].  gy: S over the
+    gradient w.r.t. the concatenated output (two-source prologue), src: S over the forward's source (BatchNorm + ReLU)."""
+    N, _, T_in, V = src.x1.shape
+    T_out = gy.x1.shape[2]
+    if V % 4:
+        gy = S(with_slack(gy.x1), with_slack(gy.x2), gy.coef, gy.coff, gy.act)
+        src = S(with_slack(src.x1), None, src.coef, src.coff, src.act)
+    nb = len(dils)
+    d = TconvDesc()
+    d.src = gy.c()
+    d.N, d.T_in, d.T_out, d.V, d.Cb, d.nb, d.KT, d.stride = N, T_in, T_out, V, Cb, nb, KT, stride
+    for b, dl in enumerate(dils):
+        d.dil[b] = int(dl)
+    mc = src.c()
+    d.mask = C.pointer(mc)
+    lib = _lib_()
+    mx = lib.tamgcn_tconv_wgrad_max_split(C.byref(d))
+    if mx <= 0:
+        raise RuntimeError('tamgcn_tconv_wgrad: no tiling for this shape')
+    blocks = nb * (1 if Cb == 16 else (Cb // 32) ** 2)
+    nsplit = max(1, min(mx, WGRAD_BLOCKS * 2 // blocks))
+    part = empty(nsplit, nb, Cb, Cb, KT, like=gy.x1)
+    d.y, d.yctot, d.ycoff = _ptr(part), nsplit, 0
+    _lib.check(lib.tamgcn_tconv_wgrad(C.byref(d), _stream()), 'tamgcn_tconv_wgrad')
+    return reduce_sum(part, nsplit, chunks=[(Cb, Cb, KT, 1)] * nb)
+
+
 WGRAD_BLOCKS = int(os.environ.get('TAMGCN_WGRAD_BLOCKS', '512'))    # workgroups a weight gradient aims at (tiles x splits)
 
 

@@ -569,6 +569,20 @@ def test_tconv_fused_branches_fwd_bwd(case):
     hc = (h1.double() - mu.double()[None, :, None, None])[:, lead: lead + nb * Cb]
     assert float((bs_[0] - dref.sum((0, 2, 3))).abs().max()) <= 2e-6 * dscale * cnt1
     assert float((bs_[1] - (dref * hc).sum((0, 2, 3))).abs().max()) <= 4e-6 * dscale * float(hc.abs().max()) * cnt1
+    # ---- weight gradients of every branch in one launch (tamgcn_tconv_wgrad)
+    wd = [w.double().clone().requires_grad_(True) for w in ws]
+    hv2 = hv.detach()
+    outs2 = []
+    for b in range(nb):
+        pad = (KT - 1) * dils[b] // 2
+        outs2.append(F.conv2d(hv2[:, lead + b * Cb: lead + (b + 1) * Cb], wd[b], None, stride=(s, 1), padding=(pad, 0), dilation=(dils[b], 1)))
+    (torch.cat(outs2, 1) * gv).sum().backward()
+    dws = ops.tconv_wgrad(S(t(g1), t(g2), t(cg), coff=4), S(t(h1), None, t(ch), coff=lead, act=1), Cb, KT, list(dils), s)
+    torch.cuda.synchronize()
+    for b in range(nb):
+        wr = wd[b].grad
+        assert tuple(dws[b].shape) == (Cb, Cb, KT, 1)
+        assert float((dws[b].double().cpu() - wr).abs().max()) <= 3e-6 * float(wr.abs().max()), b
 
 
 def test_de_tail_r16_bit_identical_beside_other_streams_in_a_graph():

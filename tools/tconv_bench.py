@@ -55,13 +55,21 @@ def run(N, Cb, T, V, s, kt=5, dils=(1, 2)):
 
     def new_b():
         ops.tconv_bwd(gy(0), Cb, kt, list(dils), s, ws, S(h, coef=coef), mu, dh, 0)
+    def old_w():
+        return [ops.wgrad(gy(b), S(h, coef=coef, coff=b * Cb, act=1), M=Cb, K=Cb, KT=kt, dil=d, stride=s, pad=(kt - 1) * d // 2) for b, d in enumerate(dils)]
+
+    def new_w():
+        return ops.tconv_wgrad(gy(0), S(h, coef=coef, act=1), Cb, kt, list(dils), s)
     fl = 2.0 * N * nb * Cb * Cb * kt * T2 * V
     by_f = 4.0 * N * (nb + 1) * Cb * (T + T2) * V
     by_b = 4.0 * N * nb * Cb * (2 * T2 + 2 * T) * V
     roof = lambda by: max(by / 6e12, fl / 157.3e12) * 1e6
     o_f, n_f, o_b, n_b = timeit(old_f), timeit(new_f), timeit(old_b), timeit(new_b)
+    o_w, n_w = timeit(old_w), timeit(new_w)
+    by_w = 4.0 * N * nb * Cb * (2 * T2 + T) * V
     print(f'Cb{Cb:3d} T{T:4d} V{V:3d} s{s} N{N:4d}: fwd old {o_f:7.1f} new {n_f:7.1f} us (roof {roof(by_f):6.1f}, {roof(by_f) / n_f:4.0%})   '
-          f'bwd old {o_b:7.1f} new {n_b:7.1f} us (roof {roof(by_b):6.1f}, {roof(by_b) / n_b:4.0%})', flush=True)
+          f'bwd old {o_b:7.1f} new {n_b:7.1f} us (roof {roof(by_b):6.1f}, {roof(by_b) / n_b:4.0%})   '
+          f'wgrad old {o_w:7.1f} new {n_w:7.1f} us (roof {roof(by_w):6.1f}, {roof(by_w) / n_w:4.0%})', flush=True)
 
 
 for Cb, T, V, s in ((16, 64, 20, 1), (32, 64, 20, 2), (32, 32, 20, 1), (64, 32, 20, 2), (64, 16, 20, 1)):
