@@ -73,6 +73,7 @@ class _Probe:
     def __getattr__(self, name):
         fn = getattr(self._lib, name)
         if not name.startswith('tamgcn_') or name in ('tamgcn_last_error', 'tamgcn_last_kernel', 'tamgcn_version', 'tamgcn_conv_nparts',
+                                                     'tamgcn_tconv_supported', 'tamgcn_tconv_nparts', 'tamgcn_tconv_wgrad_max_split',
                                                      'tamgcn_ew_nparts', 'tamgcn_ctrgc_lds_bytes', 'tamgcn_get_split_mode',
                                                      'tamgcn_set_split_mode', 'tamgcn_wgrad_max_split', 'tamgcn_ctrgc_tiled_supported',
                                                      'tamgcn_ctrgc_tiled_chunks'):
@@ -132,6 +133,18 @@ def _algorithmic(name, args):
     if name == 'tamgcn_ctrgc_tiled_de_acc':
         b = d.N * d.T * d.V * (d.S * d.Cout + 2 * d.Cout) + d.N * d.S * d.Cout * d.V * d.V
         return (4.0 * b, 2.0 * d.N * d.S * d.Cout * d.T * d.V * d.V)
+    if name in ('tamgcn_tconv_fwd', 'tamgcn_tconv_bwd', 'tamgcn_tconv_wgrad'):
+        # the MS-TCN second stage in one launch (csrc/tconv.hip): nb temporal branches of Cb channels (+ the pooled branch in the
+        # forward); DESIGN.md section 3: forward reads its source slice and writes its output slice once, the data gradient reads
+        # the two-source gradient and the ReLU-mask operand and writes once, the weight gradient reads three tensors
+        nbr = d.nb + (1 if (name == 'tamgcn_tconv_fwd' and d.pool) else 0)
+        if name == 'tamgcn_tconv_fwd':
+            b = d.N * nbr * d.Cb * (d.T_in + d.T_out) * d.V
+        elif name == 'tamgcn_tconv_bwd':
+            b = d.N * d.nb * d.Cb * (2 * d.T_out + 2 * d.T_in) * d.V
+        else:
+            b = d.N * d.nb * d.Cb * (2 * d.T_out + d.T_in) * d.V
+        return (4.0 * b, 2.0 * d.N * d.nb * d.Cb * d.Cb * d.KT * d.T_out * d.V)
     if name == 'tamgcn_ctrgc_bwd_dx3':
         b = d.N * d.T * d.V * (2 * d.Cout + d.S * d.Cout)
         f = d.N * d.S * (2.0 * d.R * d.Cout * d.V * d.V + 2.0 * d.Cout * d.T * d.V * d.V)

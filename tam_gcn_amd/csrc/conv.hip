@@ -1344,7 +1344,7 @@ extern "C" int tamgcn_conv(const tamgcn_conv_desc* d, void* stream) {
             const size_t lds = glds_lds_bytes<NS_, BK_>(d->K);                                                              \
             tg_allow_lds((const void*)conv1x1_glds_kernel<NS_, BK_, SW_>, 160 * 1024, &fl);                                 \
             hipLaunchKernelGGL((conv1x1_glds_kernel<NS_, BK_, SW_>), dim3(nblk), dim3(G_NT), lds, (hipStream_t)stream, a, p.ntt, nmt); \
-            tamgcn_note_kernel("conv1x1_glds_kernel<%d, %d%s>", NS_, BK_, SW_ ? ", swapped" : "");                          \
+            tamgcn_note_kernel("conv1x1_glds_kernel<%d, %d, %s>", NS_, BK_, SW_ ? "true" : "false");                        \
         }
         if (d->src.x2) { if (sw) TG_GLDS_CASE(2, 8, true) else TG_GLDS_CASE(2, 8, false) }
         else { if (sw) TG_GLDS_CASE(1, 16, true) else TG_GLDS_CASE(1, 16, false) }

@@ -490,7 +490,7 @@ static int tc_launch(const TcArgs& a, const TcPlan& p, int KT, dim3 grid, hipStr
         static tg_devmask done = 0;                                                                                     \
         tg_allow_lds((const void*)tconv_kernel<MT_, CT_, KT_, BWD>, 160 * 1024, &done);                                 \
         hipLaunchKernelGGL((tconv_kernel<MT_, CT_, KT_, BWD>), grid, dim3(TC_NT * MT_), p.lds, s, a);                   \
-        tamgcn_note_kernel("tconv_kernel<%d, %d, %d, %s>", MT_, CT_, KT_, BWD ? "bwd" : "fwd");                         \
+        tamgcn_note_kernel("tconv_kernel<%d, %d, %d, %s>", MT_, CT_, KT_, BWD ? "true" : "false");                         \
         return 0;                                                                                                       \
     }
     TC_CASE(1, 5, 5) TC_CASE(2, 5, 5) TC_CASE(4, 5, 5) TC_CASE(1, 3, 5) TC_CASE(2, 3, 5) TC_CASE(4, 3, 5)

@@ -30,6 +30,8 @@ def sig(name, args):
         return f'conv K{d.K} M{d.M} KT{d.KT} T{d.T_in}>{d.T_out} src{bench._src_reads(d.src)} ex{ex} wm{d.wmode} st{1 if d.stats_part else 0} s{d.stride} N{d.N}' + (f' [al{(d.src.x1 or 0) % 16}/{(d.src.x2 or 0) % 16}/{(d.w or 0) % 16} coff{d.src.coff}/{d.src.ctot} ycoff{d.ycoff}/{d.yctot} os{d.ostride} up{d.up} bc{1 if d.bcast else 0}]' if os.environ.get('RT_DETAIL') else '')
     if name == 'tamgcn_wgrad':
         return f'wgrad K{d.K} M{d.M} KT{d.KT} T{d.T_in}>{d.T_out} gy{bench._src_reads(d.gy)} src{bench._src_reads(d.src)} N{d.N}'
+    if name in ('tamgcn_tconv_fwd', 'tamgcn_tconv_bwd', 'tamgcn_tconv_wgrad'):
+        return f'{name[7:]} Cb{d.Cb} nb{d.nb} KT{d.KT} T{d.T_in}>{d.T_out} s{d.stride}' + (' +pool' if name == 'tamgcn_tconv_fwd' and d.pool else '') + f' N{d.N}'
     if name.startswith('tamgcn_ctrgc'):
         return f'{name[7:]} {d.Cin}>{d.Cout} T{d.T}'
     if name in ('tamgcn_add_act_fwd', 'tamgcn_add_act_bwd', 'tamgcn_gcn_tail_fwd', 'tamgcn_gcn_tail_bwd', 'tamgcn_gcn_mid_bwd'):
