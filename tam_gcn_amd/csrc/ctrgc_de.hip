@@ -750,7 +750,7 @@ extern "C" int tamgcn_ctrgc_bwd_de_tail(const tamgcn_ctrgc_desc* d, const float*
     TG_CHECK(d && dE && dA_part && dw4_part && db4_part && dalpha_part && dpq, "tamgcn_ctrgc_bwd_de_tail: null pointer");
     TG_CHECK(d->pq && d->w4 && d->b4 && d->alpha, "tamgcn_ctrgc_bwd_de_tail: null parameter pointer");
     TG_CHECK(d->N > 0 && d->S > 0 && d->Cout > 0 && d->Cout % 16 == 0, "tamgcn_ctrgc_bwd_de_tail: bad shape N=%d S=%d Cout=%d", d->N, d->S, d->Cout);
-    TG_CHECK(d->R >= 1 && d->R <= 32, "tamgcn_ctrgc_bwd_de_tail: R=%d outside 1..32 (use tamgcn_ctrgc_bwd_de)", d->R);
+    TG_CHECK(d->R >= 1 && d->R <= 32, "tamgcn_ctrgc_bwd_de_tail: R=%d outside 1..32 (the built range: see CTRGC.__init__ / INTEGRATION.md)", d->R);
     TailArgs a;
     TG_CHECK(groups >= 1 && d->Cout % (16 * groups) == 0, "tamgcn_ctrgc_bwd_de_tail: groups=%d must divide Cout/16=%d", groups, d->Cout / 16);
     a.N = d->N; a.Cout = d->Cout; a.S = d->S; a.R = d->R; a.G = groups;

@@ -130,7 +130,7 @@ class FusedEval:
     # ---- folded parameters, re-derived when any parameter or buffer changed ------------------------------------------
     def _state_key(self):
         m = self.model
-        mods = tuple(id(getattr(m, f'l{i}', None)) for i in range(1, 11)) + (id(m.data_bn), id(m.fc))
+        mods = tuple(id(sub_) for sub_ in m.modules())            # any replaced sub-module (model.l5.gcn1 = ...) re-collects
         if mods != self._mods:                                     # a block was replaced: re-collect what to watch
             self._mods = mods
             self._watch = list(m.parameters()) + list(m.buffers())

@@ -267,6 +267,13 @@ class CTRGC(nn.Module):
         else:
             self.rel_channels = in_channels // rel_reduction
             self.mid_channels = in_channels // mid_reduction
+        # the refinement kernels (csrc/ctrgc.hip, ctrgc_de.hip) are built for R = 4, 8, ..., 32 rel-channels: every width the
+        # reference's models use (in_channels 3 / 9 -> 8; 64 / 128 / 256 -> 8 / 16 / 32).  Say so HERE, not at the first forward
+        if self.rel_channels < 4 or self.rel_channels > 32 or self.rel_channels % 4:
+            raise NotImplementedError(
+                f'tam_gcn_amd CTRGC: rel_channels = in_channels // rel_reduction = {self.rel_channels} is not built '
+                f'(in_channels {in_channels}, rel_reduction {rel_reduction}); supported: multiples of 4 up to 32, i.e. '
+                f'in_channels // rel_reduction in {{4, 8, ..., 32}} (in_channels 3 and 9 use 8, as in the reference)')
         self.conv1 = nn.Conv2d(in_channels, self.rel_channels, kernel_size=1)
         self.conv2 = nn.Conv2d(in_channels, self.rel_channels, kernel_size=1)
         self.conv3 = nn.Conv2d(in_channels, out_channels, kernel_size=1)
@@ -487,6 +494,11 @@ class Model(nn.Module):
         from .. import f2
         if not f2.enabled() or (x.shape[0] * (x.shape[4] if x.dim() == 5 else 1)) > f2.F2_MAX_CLIPS:
             return None
+        # the engine calls the block operator directly: forward hooks on any sub-module would not fire.  A model that
+        # carries hooks (feature extraction, visualisation: visual.py:53-55 style) takes the general path, module by module
+        for mod in self.modules():
+            if mod._forward_hooks or mod._forward_pre_hooks:
+                return None
         eng = self.__dict__.get('_tamgcn_f2')
         if eng and eng.model is not self:                  # an nn.DataParallel replica carries the original's __dict__: its own engine
             eng = None

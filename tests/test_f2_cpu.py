@@ -80,8 +80,8 @@ def test_folded_blocks_equal_the_oracle(T):
 def test_unsupported_geometries_are_refused_before_any_launch():
     with pytest.raises(f2.Unsupported):
         f2.FusedEval(M.Model(**MODEL_CASES[3][1]).eval())   # NTU: 25 joints
-    blk = M.TCN_GCN_unit(60, 60, M.Model(**MODEL_CASES[1][1]).graph.A, kernel_size=5, dilations=[1, 2, 3])
-    with pytest.raises(f2.Unsupported):                    # 3 temporal branches of 12 channels: not a multiple of 16
+    blk = M.TCN_GCN_unit(65, 65, M.Model(**MODEL_CASES[1][1]).graph.A, kernel_size=5, dilations=[1, 2, 3])
+    with pytest.raises(f2.Unsupported):                    # 3 temporal branches of 13 channels: not a multiple of 16
         f2._Block(blk, torch.device('cpu'))
 
 
@@ -121,3 +121,24 @@ def test_state_key_sees_updates_through_a_param_arena():
         arena.flat.add_(0.5)
     Fn._eval_cached(m.l1.tcn1, 't', [bn], lambda: built.append(1))
     assert len(built) == 2
+
+
+def test_engine_key_follows_nested_module_replacement_and_hooks_route_away():
+    """replacing a NESTED sub-module (model.l5.gcn1) must re-collect the watched tensors, and a model with
+    forward hooks is not served by the engine (the hooks would not fire)."""
+    m = M.Model(**MODEL_CASES[1][1]).eval()
+    eng = f2.FusedEval(m)
+    k0 = eng._state_key()
+    old = m.l5.gcn1
+    m.l5.gcn1 = M.unit_gcn(64, 128, old.PA.detach().numpy())
+    k1 = eng._state_key()
+    assert k1 != k0 and any(p is q for p in eng._watch for q in m.l5.gcn1.parameters())
+    assert not any(p is q for p in eng._watch for q in old.parameters())
+
+
+def test_unsupported_rel_channels_fail_at_construction():
+    """CTRGC(72, 64) has 9 rel-channels, which the kernels are not built for: NotImplementedError when the
+    module is BUILT, with the supported set in the message (it used to surface as a RuntimeError in the first forward)."""
+    with pytest.raises(NotImplementedError, match='rel_channels'):
+        M.CTRGC(72, 64)
+    M.CTRGC(64, 64); M.CTRGC(3, 64); M.CTRGC(256, 128)
