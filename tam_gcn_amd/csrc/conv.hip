@@ -250,6 +250,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel(const ConvArgs a) {
 // Second half of the staged epilogue: rows r0..r0+RP-1 of the accumulator tile sit in LDS (Tt, pitch PT);
 // TPR threads walk one row in float4 steps: bias / broadcast / residual adds / mask / BatchNorm moments,
 // 16-byte coalesced loads and stores.  Row moments land in Ss[0..BMT) / Ss[4*BM..).
+// x / d for 0 <= x < 2^20, 4 <= d <= 1024 through the reciprocal (three VALU instead of ~25): (x + 0.5) / d is at least
+// 0.5 / d >= 5e-4 away from an integer, float rounding moves it by < 0.07 at these sizes
+__device__ __forceinline__ int tc_like_div(int x, float rcp) { return (int)(((float)x + 0.5f) * rcp); }
 template <int NTH>
 __device__ __forceinline__ void staged_rows(const ConvArgs& a, const float* Tt, int PT, int RP, int r0, int BMT, int m0, int n, int t0,
                                             int ncols, float* Ss, int Vs, int v0) {
@@ -591,11 +594,13 @@ __global__ __launch_bounds__(NTHREADS) void conv_kernel_vec(const ConvArgs a) {
 //               each B element is read by exactly one wave, so this costs 1-3 VALU per element
 //   epilogue    the staged float4 epilogue of conv_kernel_vec (staged_rows)
 // ===========================================================================
-// x / d for 0 <= x < 2^20, 4 <= d <= 1024 through the reciprocal (three VALU instead of ~25): (x + 0.5) / d is at least
-// 0.5 / d >= 5e-4 away from an integer, float rounding moves it by < 0.07 at these sizes
-__device__ __forceinline__ int tc_like_div(int x, float rcp) { return (int)(((float)x + 0.5f) * rcp); }
 
-constexpr int G_NT = 512, G_BMT = 64, G_PA = 80, G_PBMAX = 320, G_NST = 3, G_CWT = 5, G_MT = 2;
+// TG_KO: knock-out side builds for tools/conv_knockout.py (what each part of the kernel costs; results are WRONG by design):
+// 1 no epilogue, 2 no prologue arithmetic on the B fragments, 4 no A DMA, 8 no B DMA, 16 no MFMAs, 32 no fragment reads
+#ifndef TG_KO
+#define TG_KO 0
+#endif
+constexpr int G_NT = 512, G_BMT = 64, G_PA = 80, G_PBMAX = 320, G_NST = 3, G_CWT = 5;
 
 typedef __attribute__((address_space(1))) const void* tg_gptr;
 typedef __attribute__((address_space(3))) void* tg_lptr;
@@ -610,20 +615,22 @@ __device__ __forceinline__ void wait_vmcnt(int n) {     // n is wave-uniform
     }
 }
 
-// SW (operand-swapped product): the activation columns are the MFMA rows and the output channels its columns, so a lane's
-// four accumulator registers are FOUR CONSECUTIVE columns of one channel: the epilogue (bias, eval-mode affine, broadcast
-// term, residual adds, ReLU, BatchNorm moments) runs straight from the registers with 16-byte accesses -- no LDS staging
-// passes, none of their four barriers (28 % of a workgroup's lifetime at 64 channels, profiles/r03_conv_phases.txt).  The
-// inner loop is the same (same fragments, operands exchanged).  Launches with a ReLU mask or a centring operand (the k x 1
-// data gradients of ST-GCN) keep the staged form (SW = false).
-template <int NSRC, int BK, bool SW>
-__global__ __launch_bounds__(G_NT, SW ? 4 : 2) void conv1x1_glds_kernel(const ConvArgs a, int ntt, int nmt) {
+// NW = waves per workgroup: 8 (2 x 4 waves of 32 rows x 80 columns, two accumulator row tiles) or 4 (1 x 4 waves of 64 rows x 80
+// columns, four row tiles).  On this chip a VALU instruction does not run BESIDE an fp32 MFMA, it runs INSTEAD of one
+// (tools/probes/coissue_probe.hip: 16 MFMAs + 64 v_fma per SIMD take 778 cycles where the MFMAs alone take 569; issued from another
+// wave of the SIMD it is worse), so what bounds this kernel is VALU instructions per MFMA: the prologue and the address
+// arithmetic of a B fragment are paid once per wave that reads it -- four row tiles per wave halve both.
+// PRO: the source carries a prologue (coefficients, second source or ReLU).  A plain tensor (the dx <- dx3 GEMMs, K = 3 C) needs neither
+// the [3][K] coefficient table -- which alone pushed K >= 384 past 80 KB, i.e. to ONE workgroup per CU -- nor the VALU on the fragments.
+template <int NSRC, int BK, bool PRO, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void conv1x1_glds_kernel(const ConvArgs a, int ntt, int nmt) {
+    constexpr int G_NT = NW * 64, G_MT = 16 / NW;                 // threads; row tiles per wave
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int STG = BK * G_PBMAX * NSRC + BK * G_PA;          // floats per stage
-    constexpr int NAI = BK / 8;                                   // A pieces per wave and chunk
-    constexpr int MAXB = (NSRC * (BK / 4) * 5 + 7) / 8;           // B pieces per wave and chunk (upper bound)
-    float* cf = smem + G_NST * STG;                               // [3][K]
-    float* Ss = cf + 3 * a.K;                                     // [2][4*BM] row moments
+    constexpr int NAI = BK / NW;                                  // A pieces per wave and chunk
+    constexpr int MAXB = (NSRC * (BK / 4) * 5 + NW - 1) / NW;     // B pieces per wave and chunk (upper bound)
+    float* cf = smem + G_NST * STG;                               // [3][K] (PRO only)
+    float* Ss = cf + (PRO ? 3 * a.K : 0);                         // [2][4*BM] row moments
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kq = lane >> 4, wm = wave >> 2, wn = wave & 3;
@@ -652,7 +659,7 @@ __global__ __launch_bounds__(G_NT, SW ? 4 : 2) void conv1x1_glds_kernel(const Co
     int nissue = 0;                                               // + the A pieces, below
 #pragma unroll
     for (int i = 0; i < MAXB; ++i) {
-        const int id = wave + i * 8;
+        const int id = wave + i * NW;
         const bool idok = id < NSRC * NI1;
         const int src = idok ? id / NI1 : 0;
         const int rem = id - src * NI1;
@@ -694,7 +701,8 @@ __global__ __launch_bounds__(G_NT, SW ? 4 : 2) void conv1x1_glds_kernel(const Co
     auto issue = [&](int c) {
         float* st = smem + (c % G_NST) * STG;
         const int k0 = c * BK;
-        if (wm0) {
+        if (TG_KO & 4) {
+        } else if (wm0) {
             if (a_on) {
                 if (a_ok) __builtin_amdgcn_global_load_lds((tg_gptr)(wbase + k0), (tg_lptr)(st + BK * G_PBMAX * NSRC + a_dst0), 16, 0, 0);
             }
@@ -707,7 +715,7 @@ __global__ __launch_bounds__(G_NT, SW ? 4 : 2) void conv1x1_glds_kernel(const Co
             }
         }
 #pragma unroll
-        for (int i = 0; i < MAXB; ++i) {
+        for (int i = 0; i < ((TG_KO & 8) ? 0 : MAXB); ++i) {
             if (b_on[i]) {
                 const float* base = (NSRC == 2 && (b_rel[i] & 0x40000000)) ? xb2 : xb1;
                 const float* gp = base + (long long)k0 * TV + (b_rel[i] & 0x3fffffff);
@@ -725,15 +733,18 @@ __global__ __launch_bounds__(G_NT, SW ? 4 : 2) void conv1x1_glds_kernel(const Co
         int sl = col - (kq & 1) * rot;
         bslot[c] = sl < 0 ? sl + LB : sl;
     }
-    int aoff[BK / 4][G_MT];                                       // A fragment offsets inside a stage's A image
+    // Fragment addresses = (per-lane base, 2 + 5 registers) + (a wave-uniform offset per stage and k4 step, recomputed on the
+    // scalar unit and hidden from the optimiser: left visible, hipcc hoists all 4 x 7 sums out of the K loop into registers).
+    int vb[G_CWT], va[G_MT];
 #pragma unroll
-    for (int k4 = 0; k4 < BK / 4; ++k4)
+    for (int c = 0; c < G_CWT; ++c) vb[c] = kq * LB + bslot[c];
 #pragma unroll
-        for (int mt = 0; mt < G_MT; ++mt) {
-            const int m = wm * 32 + mt * 16 + j;
-            const int f = BK == 16 ? (m >> 1) & 3 : (m >> 2) & 1;
-            aoff[k4][mt] = wm0 ? m * BK + 4 * (k4 ^ f) + kq : (k4 * 4 + kq) * G_PA + m;
-        }
+    for (int mt = 0; mt < G_MT; ++mt) {
+        const int m = wm * (G_MT * 16) + mt * 16 + j;
+        const int f = BK == 16 ? (m >> 1) & 3 : (m >> 2) & 1;
+        va[mt] = wm0 ? m * BK + 4 * f + kq : kq * G_PA + m;         // wmode 0: quad k4 of row m sits at k4 ^ f, i.e. base ^ (4 k4)
+    }
+    const int axor = wm0 ? 4 : 0, aadd = wm0 ? 0 : 4 * G_PA;
     f32x4 acc[G_MT][G_CWT];
 #pragma unroll
     for (int mt = 0; mt < G_MT; ++mt)
@@ -745,9 +756,9 @@ __global__ __launch_bounds__(G_NT, SW ? 4 : 2) void conv1x1_glds_kernel(const Co
     // The prologue coefficients are requested FIRST and the whole ring (three chunks) right behind them: vmcnt retires in
     // order, so waiting for "all but the chunks" is waiting for the coefficients only, and a raw barrier publishes them
     // (__syncthreads would drain the chunks too -- the kernel used to start its K loop with an empty third stage).
-    float cfr[2][3];
+    float cfr[1024 / G_NT][3];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {                                 // K <= 1024 (host-checked)
+    for (int i = 0; i < (PRO ? 1024 / G_NT : 0); ++i) {                     // K <= 1024 (host-checked)
         const int e = tid + i * G_NT, ch = a.src.coff + (e < K ? e : 0);
         cfr[i][0] = a.src.coef ? a.src.coef[ch] : 1.f;
         cfr[i][1] = (a.src.coef && a.src.x2) ? a.src.coef[a.src.ctot + ch] : 0.f;
@@ -759,167 +770,113 @@ __global__ __launch_bounds__(G_NT, SW ? 4 : 2) void conv1x1_glds_kernel(const Co
     if (nch > 2) issue(2);
     wait_vmcnt(npre * nissue);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < (PRO ? 1024 / G_NT : 0); ++i) {
         const int e = tid + i * G_NT;
         if (e < K) { cf[e] = cfr[i][0]; cf[K + e] = cfr[i][1]; cf[2 * K + e] = cfr[i][2]; }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     TG_T(tt1); TG_ACC(0, tt1 - tt0);
-    for (int c = 0; c < nch; ++c) {
-        TG_T(ta);
-        wait_vmcnt(c == 0 ? (npre - 1) * nissue : (c + 1 < nch ? nissue : 0));   // this wave's pieces of chunk c have landed
-        TG_T(tb); TG_ACC(2, tb - ta);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // everyone's have; chunk c-1 fully consumed
-        TG_T(tc); TG_ACC(4, tc - tb);
-        if (c > 0 && c + 2 < nch) issue(c + 2);
-        TG_T(td); TG_ACC(5, td - tc);
-        const float* st = smem + (c % G_NST) * STG;
-        const float* As = st + BK * G_PBMAX * NSRC;
+    // Software-pipelined fragment reads.  Left to itself hipcc emits "8 ds_reads, s_waitcnt lgkmcnt(0), VALU, 8 MFMAs" per
+    // k4 step; round-robin issue keeps the waves of a SIMD in lockstep, so they all wait for LDS together and the matrix
+    // pipe idles for every round trip (tools/conv_knockout.py: reads + MFMAs without any DMA take 350 us where the MFMAs
+    // alone take 229, K768 -> M256).  Here the reads of step i + 1 are issued in front of step i's MFMAs (two register
+    // sets), across the chunk boundary too: the barrier that publishes chunk c + 1 sits in front of chunk c's LAST step,
+    // whose fragments are already in registers -- so stage c is free there and chunk c + 3 is requested into it.
+    constexpr int NK = BK / 4;
+    constexpr int NRD = G_MT + G_CWT * NSRC + (PRO ? NSRC + 1 : 0);   // LDS reads per step
+    float fa[2][G_MT], bvs[2][G_CWT];                                 // the fragments MFMAs read: two sets
+    float fb[G_CWT], fb2[NSRC == 2 ? G_CWT : 1], fc[3];               // raw reads of the NEXT step (prologue not applied yet)
+    const int cfo = G_NST * STG;                                      // float index of the coefficient table
+    auto rd = [&](int set, int stage, int kg, int k4) {                // kg: the chunk's first contraction row
+        int sb = stage * STG + k4 * 4 * LB, sa = stage * STG + BK * G_PBMAX * NSRC + k4 * aadd, sc = cfo + kg + k4 * 4, sx = k4 * axor;
+        asm volatile("" : "+s"(sb), "+s"(sa), "+s"(sc), "+s"(sx));
+#pragma unroll
+        for (int mt = 0; mt < G_MT; ++mt) fa[set][mt] = smem[sa + (va[mt] ^ sx)];
+        if constexpr (PRO && !(TG_KO & 2)) {
+            fc[0] = smem[sc + kq]; fc[2] = smem[sc + 2 * K + kq];
+            if constexpr (NSRC == 2) fc[1] = smem[sc + K + kq];
+        }
+#pragma unroll
+        for (int cc = 0; cc < G_CWT; ++cc) {
+            fb[cc] = smem[sb + vb[cc]];
+            if constexpr (NSRC == 2) fb2[cc] = smem[sb + vb[cc] + BK * G_PBMAX];
+        }
+    };
+    auto pro = [&](int set) {
+#pragma unroll
+        for (int cc = 0; cc < G_CWT; ++cc) {
+            if constexpr (!PRO) bvs[set][cc] = fb[cc];
+            else if (TG_KO & 2) bvs[set][cc] = fb[cc] + (NSRC == 2 ? fb2[cc] : 0.f);
+            else if constexpr (NSRC == 2) bvs[set][cc] = fmaxf(fmaf(fc[0], fb[cc], fmaf(fc[1], fb2[cc], fc[2])), lo);
+            else bvs[set][cc] = fmaxf(fmaf(fc[0], fb[cc], fc[2]), lo);
+        }
+    };
+    // Pinning the order.  Neither sched_barrier nor sched_group_barrier holds it (instruction selection lets the unchained
+    // MFMA nodes float across them).  An empty asm that redefines registers is a real dependence:
+    //   mm:  the fragments of this step pass through one AFTER the next step's reads were issued ("memory": the loads stay above)
+    //   fin: every accumulator and the raw reads pass through one, the prologue consumes from it -- hipcc puts the
+    //        s_waitcnt for the reads in front of it, i.e. behind ten MFMAs' issue; a third keeps the prologue from sinking
+    static_assert((G_MT == 2 || G_MT == 4) && G_CWT == 5, "operand lists below");
+#define TG_ACC5(mt_) "+v"(acc[mt_][0]), "+v"(acc[mt_][1]), "+v"(acc[mt_][2]), "+v"(acc[mt_][3]), "+v"(acc[mt_][4])
+#define TG_V5(x_) "+v"(x_[0]), "+v"(x_[1]), "+v"(x_[2]), "+v"(x_[3]), "+v"(x_[4])
+    auto mm = [&](int cur) {
+        if constexpr (G_MT == 2) asm volatile("" : "+v"(fa[cur][0]), "+v"(fa[cur][1]), TG_V5(bvs[cur]) :: "memory");
+        else asm volatile("" : "+v"(fa[cur][0]), "+v"(fa[cur][1]), "+v"(fa[cur][2]), "+v"(fa[cur][3]), TG_V5(bvs[cur]) :: "memory");
+#pragma unroll
+        for (int cc = 0; cc < G_CWT; ++cc)
+#pragma unroll
+            for (int mt = 0; mt < G_MT; ++mt) acc[mt][cc] = mfma16(fa[cur][mt], bvs[cur][cc], acc[mt][cc]);
+    };
+    auto fin = [&](int nxt) {
+        if constexpr (G_MT == 4) asm volatile("" : TG_ACC5(2), TG_ACC5(3) :: "memory");   // (volatile asms keep their order)
+        if constexpr (NSRC == 2) asm volatile("" : TG_ACC5(0), TG_ACC5(1), TG_V5(fb), TG_V5(fb2) :: "memory");
+        else asm volatile("" : TG_ACC5(0), TG_ACC5(1), TG_V5(fb) :: "memory");
+        pro(nxt);
+        asm volatile("" : TG_V5(bvs[nxt]));
+    };
+#undef TG_ACC5
+#undef TG_V5
+    wait_vmcnt((npre - 1) * nissue);                                  // this wave's pieces of chunk 0 have landed
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // everyone's have
+    rd(0, 0, 0, 0);
+    pro(0);
+    int stg = 0;
+    for (int c = 0; c + 1 < nch; ++c) {                               // every chunk but the last: its last step crosses into the next
         const int k0 = c * BK;
 #pragma unroll
-        for (int k4 = 0; k4 < BK / 4; ++k4) {
-            const int k = k4 * 4 + kq;
-            float av[G_MT], bv[G_CWT];
-#pragma unroll
-            for (int mt = 0; mt < G_MT; ++mt) av[mt] = As[aoff[k4][mt]];
-            const float c1 = cf[k0 + k], c0 = cf[2 * K + k0 + k];
-            if constexpr (NSRC == 2) {
-                const float c2 = cf[K + k0 + k];
-#pragma unroll
-                for (int cc = 0; cc < G_CWT; ++cc) {
-                    float v1 = st[k * LB + bslot[cc]], v2 = st[BK * G_PBMAX + k * LB + bslot[cc]];
-                    bv[cc] = fmaxf(fmaf(c1, v1, fmaf(c2, v2, c0)), lo);
-                }
-            } else {
-#pragma unroll
-                for (int cc = 0; cc < G_CWT; ++cc) bv[cc] = fmaxf(fmaf(c1, st[k * LB + bslot[cc]], c0), lo);
-            }
-#pragma unroll
-            for (int cc = 0; cc < G_CWT; ++cc)
-#pragma unroll
-                for (int mt = 0; mt < G_MT; ++mt) acc[mt][cc] = SW ? mfma16(bv[cc], av[mt], acc[mt][cc]) : mfma16(av[mt], bv[cc], acc[mt][cc]);
+        for (int s_ = 0; s_ + 1 < NK; ++s_) {
+            rd((s_ & 1) ^ 1, stg, k0, s_ + 1);
+            mm(s_ & 1);
+            fin((s_ & 1) ^ 1);
         }
-        TG_T(te); TG_ACC(6, te - td);
+        wait_vmcnt(c + 2 < nch ? nissue : 0);                         // this wave's pieces of chunk c + 1 have landed
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // everyone's have; every fragment of chunk c is in registers
+        if (c + 3 < nch) issue(c + 3);
+        stg = stg == G_NST - 1 ? 0 : stg + 1;
+        rd(NK & 1, stg, k0 + BK, 0);                                  // NK is even: the next chunk starts on set 0 again
+        mm((NK - 1) & 1);
+        fin(NK & 1);
+    }
+    {
+        const int k0 = (nch - 1) * BK;
+#pragma unroll
+        for (int s_ = 0; s_ < NK; ++s_) {
+            if (s_ + 1 < NK) rd((s_ & 1) ^ 1, stg, k0, s_ + 1);
+            mm(s_ & 1);
+            if (s_ + 1 < NK) fin((s_ & 1) ^ 1);
+        }
     }
     TG_T(tg0);
 
-    if constexpr (SW) {
-        // ---- epilogue from the registers: lane (j, kq) holds, per (row tile mt, column tile c), columns
-        // (wn*CWT + c)*16 + 4*kq + r (r = 0..3) of channel m0 + wm*32 + mt*16 + j.  Every load of the epilogue (per-channel
-        // constants, residual / broadcast operands) is issued and consumed BEFORE the first store: vmcnt retires in order,
-        // a load behind a store waits for that store.
-        const float plo = a.post_act == 1 ? 0.f : -__builtin_inff();
-        const float rV = 1.0f / (float)V;
-        const bool contig = a.ostride == 1;                   // a tile's columns are one contiguous run of the output row
-        const bool vec_y = contig || (V & 3) == 0;             // a group of four columns is one 16-byte access
-        const bool vec_b = (V & 3) == 0;
-        float q1[G_MT], q2[G_MT];
-        unsigned offs[G_MT][G_CWT];                           // element offset of the group inside y (host: < 2^32 elements)
-#pragma unroll
-        for (int mt = 0; mt < G_MT; ++mt) {
-            const int m = m0 + wm * 32 + mt * 16 + j;
-            const bool mok = m < a.M;
-            const int mm = mok ? m : 0;
-            const float bia = a.bias ? a.bias[mm] : 0.f;
-            const float pc1 = a.post_coef ? a.post_coef[a.ycoff + mm] : 1.f, pc0 = a.post_coef ? a.post_coef[2 * a.post_ctot + a.ycoff + mm] : 0.f;
-            const unsigned ybase = (unsigned)(((long long)n * a.yctot + a.ycoff + mm) * a.T_y * V);
-            const float* bc = a.bcast ? a.bcast + ((long long)mm * a.N + n) * V : nullptr;
-            float p1 = 0.f, p2 = 0.f;
-            f32x4 t1[G_CWT], t2[G_CWT];
-#pragma unroll
-            for (int c = 0; c < G_CWT; ++c) {                 // unconditional loads: an inactive group re-reads the tile's first one
-                const int col0 = (wn * G_CWT + c) * 16 + 4 * kq;
-                const int cs_ = (mok && col0 + 4 <= ncols) ? col0 : 0;
-                const int fr = tc_like_div(cs_, rV), v = cs_ - fr * V;
-                offs[mt][c] = ybase + (unsigned)(contig ? t0 * V + cs_ : (t0 + fr) * a.ostride * V + v);
-                t1[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                t2[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (vec_y) {
-                    if (a.add1) t1[c] = *reinterpret_cast<const f32x4*>(a.add1 + offs[mt][c]);
-                    if (a.add2) t2[c] = *reinterpret_cast<const f32x4*>(a.add2 + offs[mt][c]);
-                }
-                if (bc && vec_b) {
-                    const f32x4 tb = *reinterpret_cast<const f32x4*>(bc + v);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) t2[c][r] = fmaf(tb[r], a.bcast_scale, t2[c][r]);
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < G_CWT; ++c) {
-                const int col0 = (wn * G_CWT + c) * 16 + 4 * kq;
-                f32x4 val = acc[mt][c];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) val[r] = fmaf(pc1, val[r] + bia, pc0);
-                if (mok && col0 + 4 <= ncols && vec_y && (!bc || vec_b)) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) val[r] = fmaxf(val[r] + t1[c][r] + t2[c][r], plo);
-                    p1 += (val[0] + val[1]) + (val[2] + val[3]);
-                    p2 = fmaf(val[0], val[0], fmaf(val[1], val[1], fmaf(val[2], val[2], fmaf(val[3], val[3], p2))));
-                } else if (mok && col0 < ncols) {
-                    // element-wise: the tile's last, partial group; rows of V % 4 != 0 joints with a strided output or a
-                    // broadcast term (a group may leave its frame).  Finished here, stored below with the others.
-                    for (int r = 0; r < 4 && col0 + r < ncols; ++r) {
-                        const int ci = col0 + r, fi = tc_like_div(ci, rV), vi = ci - fi * V;
-                        const unsigned o = ybase + (unsigned)(contig ? t0 * V + ci : (t0 + fi) * a.ostride * V + vi);
-                        float x = val[r];
-                        if (bc) x = fmaf(bc[vi], a.bcast_scale, x);
-                        if (a.add1) x += a.add1[o];
-                        if (a.add2) x += a.add2[o];
-                        x = fmaxf(x, plo);
-                        val[r] = x;
-                        p1 += x;
-                        p2 = fmaf(x, x, p2);
-                    }
-                }
-                acc[mt][c] = val;
-            }
-            q1[mt] = p1; q2[mt] = p2;
-        }
-        // the stores, all of them behind the last load
-#pragma unroll
-        for (int mt = 0; mt < G_MT; ++mt) {
-            const bool mok = m0 + wm * 32 + mt * 16 + j < a.M;
-#pragma unroll
-            for (int c = 0; c < G_CWT; ++c) {
-                const int col0 = (wn * G_CWT + c) * 16 + 4 * kq;
-                if (!mok || col0 >= ncols) continue;
-                if (col0 + 4 <= ncols && vec_y) *reinterpret_cast<f32x4*>(a.y + offs[mt][c]) = acc[mt][c];
-                else {
-                    const unsigned ybase = (unsigned)(((long long)n * a.yctot + a.ycoff + m0 + wm * 32 + mt * 16 + j) * a.T_y * V);
-                    for (int r = 0; r < 4 && col0 + r < ncols; ++r) {
-                        const int ci = col0 + r, fi = tc_like_div(ci, rV), vi = ci - fi * V;
-                        a.y[ybase + (unsigned)(contig ? t0 * V + ci : (t0 + fi) * a.ostride * V + vi)] = acc[mt][c][r];
-                    }
-                }
-            }
-        }
-        if (a.stats_part) {
-            // row moments: the four kq lanes of a channel, then the four column waves through LDS (the ring is dead)
-            __syncthreads();
-            float* Sd = smem;                                 // [2][4][64]
-#pragma unroll
-            for (int mt = 0; mt < G_MT; ++mt) {
-                float u1 = q1[mt], u2 = q2[mt];
-                u1 += __shfl_xor(u1, 16); u1 += __shfl_xor(u1, 32);
-                u2 += __shfl_xor(u2, 16); u2 += __shfl_xor(u2, 32);
-                if (kq == 0) {
-                    Sd[(0 * 4 + wn) * G_BMT + wm * 32 + mt * 16 + j] = u1;
-                    Sd[(1 * 4 + wn) * G_BMT + wm * 32 + mt * 16 + j] = u2;
-                }
-            }
-            __syncthreads();
-            if (tid < 2 * G_BMT) {
-                const int stt = tid / G_BMT, row = tid - stt * G_BMT;
-                const int m = m0 + row;
-                const float tot = (Sd[(stt * 4 + 0) * G_BMT + row] + Sd[(stt * 4 + 1) * G_BMT + row]) +
-                                  (Sd[(stt * 4 + 2) * G_BMT + row] + Sd[(stt * 4 + 3) * G_BMT + row]);
-                if (m < a.M) a.stats_part[((long long)stt * a.stats_ctot + a.stats_coff + m) * a.nparts + g] = tot;
-            }
-        }
-        TG_T(tg1s); TG_ACC(7, tg1s - tg0); TG_ACC(8, tg1s - tt0); TG_ACC(9, 1);
+#if TG_KO & 1
+    {
+        float ssum = 0.f;
+        for (int mt = 0; mt < G_MT; ++mt)
+            for (int c = 0; c < G_CWT; ++c) ssum += acc[mt][c][0] + acc[mt][c][1] + acc[mt][c][2] + acc[mt][c][3];
+        if (ssum == 123.456f) a.y[tid] = ssum;
         return;
     }
-
+#endif
     // ---- staged epilogue (two passes of 32 rows through the dead stage buffers)
     constexpr int PT = G_CWT * 64 + 4, RP = 32;
     float* Tt = smem;
@@ -928,15 +885,17 @@ __global__ __launch_bounds__(G_NT, SW ? 4 : 2) void conv1x1_glds_kernel(const Co
     }
     for (int r0 = 0; r0 < G_BMT; r0 += RP) {
         __syncthreads();
-        if (wm * 32 == r0) {
 #pragma unroll
-            for (int mt = 0; mt < G_MT; ++mt)
+        for (int mt = 0; mt < G_MT; ++mt) {
+            const int rl = wm * (G_MT * 16) + mt * 16 - r0;       // first local row of this row tile in the pass
+            if (rl >= 0 && rl < RP) {
 #pragma unroll
                 for (int c = 0; c < G_CWT; ++c) {
                     const int col = (wn * G_CWT + c) * 16 + j;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) Tt[(mt * 16 + kq * 4 + r) * PT + col] = acc[mt][c][r];
+                    for (int r = 0; r < 4; ++r) Tt[(rl + kq * 4 + r) * PT + col] = acc[mt][c][r];
                 }
+            }
         }
         __syncthreads();
         staged_rows<G_NT>(a, Tt, PT, RP, r0, G_BMT, m0, n, t0, ncols, Ss, V, 0);
@@ -1198,8 +1157,8 @@ __global__ __launch_bounds__(G_NT) void conv1x1_glds_split_kernel(const ConvArgs
 }
 
 template <int NSRC, int BK>
-constexpr size_t glds_lds_bytes(int K) {
-    return sizeof(float) * ((size_t)G_NST * (BK * G_PBMAX * NSRC + BK * G_PA) + 3 * (size_t)K + 2 * 4 * BM);
+constexpr size_t glds_lds_bytes(int K, bool pro = true) {
+    return sizeof(float) * ((size_t)G_NST * (BK * G_PBMAX * NSRC + BK * G_PA) + (pro ? 3 * (size_t)K : 0) + 2 * 4 * BM);
 }
 
 struct ConvPlan { int BT, CW, TIN, lstride, sB, LB, pitchB, ntt, bk, mt, cwt, Vs, Vp, nsl; bool vec, flat; size_t lds; };
@@ -1329,25 +1288,25 @@ extern "C" int tamgcn_conv(const tamgcn_conv_desc* d, void* stream) {
     } else if (glds) {
         const int nmt = ceil_div(d->M, G_BMT);
         const unsigned nblk = (unsigned)(d->N * p.ntt * nmt);
-        // The register epilogue (operand-swapped product) is an OPT-IN (TAMGCN_CONV_SWAP=1): built for VERDICT r03 item 4 and
-        // measured against the staged epilogue at the step's eleven signatures (tools/conv_swap_bench.py,
-        // profiles/r04_conv_swap_ab.txt, two interleaved rounds): forward convs with moments 0 .. +1 % (no change), two-source
-        // data gradients 10-17 % SLOWER (62 -> 72 us at 64 channels), the K >= 384 dx GEMMs with a broadcast term and two
-        // residual adds 5 % faster, the K = 192 one 3 % slower.  With two workgroups per CU a workgroup's staged epilogue runs
-        // under the other's MFMAs; it was never on the critical path.
-        static int sw_env = -1;
-        if (sw_env < 0) { const char* e = getenv("TAMGCN_CONV_SWAP"); sw_env = e ? atoi(e) : 0; }
-        const bool sw = sw_env != 0 && !d->mask && !d->aux;
-#define TG_GLDS_CASE(NS_, BK_, SW_)                                                                                       \
+        // (Round 4 also built this kernel with an operand-swapped product and a register epilogue, VERDICT r03 item 4: forward
+        // convs +-1 %, two-source data gradients 10-17 % slower, K >= 384 dx GEMMs 5 % faster -- profiles/r04_conv_swap_ab.txt.
+        // Removed again when the kernel went to four row tiles per wave: 80 accumulator registers leave no room for it.)
+        static int nw_env = -1;
+        if (nw_env < 0) { const char* e = getenv("TAMGCN_CONV_WAVES"); nw_env = e ? atoi(e) : 8; }
+        const bool pro = d->src.coef || d->src.x2 || d->src.act;
+#define TG_GLDS_CASE(NS_, BK_, PRO_, NW_)                                                                                 \
         {                                                                                                                   \
             static tg_devmask fl = 0;                                                                                       \
-            const size_t lds = glds_lds_bytes<NS_, BK_>(d->K);                                                              \
-            tg_allow_lds((const void*)conv1x1_glds_kernel<NS_, BK_, SW_>, 160 * 1024, &fl);                                 \
-            hipLaunchKernelGGL((conv1x1_glds_kernel<NS_, BK_, SW_>), dim3(nblk), dim3(G_NT), lds, (hipStream_t)stream, a, p.ntt, nmt); \
-            tamgcn_note_kernel("conv1x1_glds_kernel<%d, %d, %s>", NS_, BK_, SW_ ? "true" : "false");                        \
+            const size_t lds = glds_lds_bytes<NS_, BK_>(d->K, PRO_);                                                        \
+            tg_allow_lds((const void*)conv1x1_glds_kernel<NS_, BK_, PRO_, NW_>, 160 * 1024, &fl);                           \
+            hipLaunchKernelGGL((conv1x1_glds_kernel<NS_, BK_, PRO_, NW_>), dim3(nblk), dim3(NW_ * 64), lds, (hipStream_t)stream, a, p.ntt, nmt); \
+            tamgcn_note_kernel("conv1x1_glds_kernel<%d, %d, %s, %d>", NS_, BK_, PRO_ ? "true" : "false", NW_);              \
         }
-        if (d->src.x2) { if (sw) TG_GLDS_CASE(2, 8, true) else TG_GLDS_CASE(2, 8, false) }
-        else { if (sw) TG_GLDS_CASE(1, 16, true) else TG_GLDS_CASE(1, 16, false) }
+        if (nw_env != 4) {
+            if (d->src.x2) TG_GLDS_CASE(2, 8, true, 8) else if (pro) TG_GLDS_CASE(1, 16, true, 8) else TG_GLDS_CASE(1, 16, false, 8)
+        } else {
+            if (d->src.x2) TG_GLDS_CASE(2, 8, true, 4) else if (pro) TG_GLDS_CASE(1, 16, true, 4) else TG_GLDS_CASE(1, 16, false, 4)
+        }
 #undef TG_GLDS_CASE
     } else if (p.vec) {
         dim3 gridv(p.ntt * p.nsl, ceil_div(d->M, 16 * p.mt), d->N);

@@ -341,19 +341,20 @@ def test_split_fp32_modes_against_fp64(mode, bar):
         assert max(errs['wgrad']) > 1e-6
 
 
-def test_pointwise_gemm_register_epilogue_variant():
-    """TAMGCN_CONV_SWAP=1 (read once per process): the 1x1 LDS-DMA GEMM as an operand-swapped product with its epilogue
-    straight from the accumulators -- kept as an opt-in after it measured no faster (csrc/conv.hip, profiles/r04_conv_swap_ab.txt).
-    The conv / pointwise primitive tests of this file, in a child process with the switch on."""
+def test_pointwise_gemm_four_wave_layout():
+    """TAMGCN_CONV_WAVES=4 (read once per process): the 1x1 LDS-DMA GEMM with 1 x 4 waves of four row tiles instead of the default
+    2 x 4 waves of two -- the A/B arm of tools/conv_knockout.py (half the prologue / address VALU per MFMA, but its epilogue is
+    slower: measured behind the default at every signature of the step).  The conv / pointwise primitive tests of this file, in a child
+    process with the switch on."""
     import os
     import subprocess
     import sys
-    if os.environ.get('TAMGCN_CONV_SWAP') == '1':
+    if os.environ.get('TAMGCN_CONV_WAVES') == '4':
         pytest.skip('already inside the child run')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-m', 'gpu', '-x', '-q', '-k',
                           'conv_fwd_bwd_wgrad or pointwise_dma or prologue_slices'], cwd=root,
-                         env=dict(os.environ, TAMGCN_CONV_SWAP='1'), capture_output=True, text=True, timeout=600)
+                         env=dict(os.environ, TAMGCN_CONV_WAVES='4'), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
 
 

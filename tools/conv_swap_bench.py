@@ -1,4 +1,4 @@
-"""GPU-box tool: the 1x1 LDS-DMA GEMM with the register epilogue (operand-swapped product, TAMGCN_CONV_SWAP=1, default) against
+"""GPU-box tool: the 1x1 LDS-DMA GEMM at the step's launch signatures (`arm`); round 4 used it for the register epilogue (TAMGCN_CONV_SWAP, since removed) against
 the LDS-staged epilogue (TAMGCN_CONV_SWAP=0) at the step's launch signatures (256 clips, V = 20).  One process per arm
 (the switch is read once)."""
 import os, subprocess, sys
