@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TAMGCN_VERSION 400          /* round 4: bumped on every change of a struct layout, signature or documented semantics */
+#define TAMGCN_VERSION 401          /* round 4: bumped on every change of a struct layout, signature or documented semantics */
 #define TAMGCN_MAX_SUBSETS 3
 #define TAMGCN_MAX_V 32             /* joints supported by the LDS-resident CTRGC tiles (V in {20, 25}); V in {32, 64}: tamgcn_ctrgc_tiled_* */
 
@@ -170,6 +170,12 @@ int tamgcn_bn_fwd_finalize(const float* part, int part_ctot, int part_coff, int 
                            float* running_mean, float* running_var, long long* num_batches_tracked,
                            float momentum, float eps, int training,
                            float* coef, float* save, int coef_ctot, int coef_coff, int C, void* stream);
+
+/* Coefficients of unit_gcn's offset_conv input diff = down(x) - bn(y) (reference models/ctrgcn.py:256-258) as a two-source
+ * prologue c1*x1 + c2*x2 + c0 from the [3][C] sets tamgcn_bn_fwd_finalize wrote for down's BatchNorm (coef_d) and bn (coef_y):
+ *   mode 0 (x1 = down's conv output, x2 = y):  (cd[0], -cy[0], cd[2] - cy[2])
+ *   mode 1 (down = identity, x1 = x, x2 = y):  (1, -cy[0], -cy[2])          mode 2 (no residual, x1 = y):  (-cy[0], 0, -cy[2]) */
+int tamgcn_coef_diff(const float* coef_d, const float* coef_y, float* out, int C, int mode, void* stream);
 
 /* part = [2][part_ctot][nparts] partial sums of (dz, dz*(x_pre - mean)) per channel; every backward
  * reducer below centres by the saved batch mean (save[0]) so that dgamma has no cancellation.

@@ -121,6 +121,7 @@ SIGNATURES = {
     'tamgcn_bn_fwd_finalize': (_i, [_p, _i, _i, _i, _d, _p, _p, _p, _p, _p, _f, _f, _i, _p, _p, _i, _i, _i, _p]),
     'tamgcn_bn_bwd_finalize': (_i, [_p, _i, _i, _i, _d, _p, _p, _i, _i, _i, _p, _p, _p, _p, _i, _i, _i, _p]),
     'tamgcn_bn_fwd_finalize_multi': (_i, [C.POINTER(BnFwdDesc), _i, _p]),
+    'tamgcn_coef_diff': (_i, [_p, _p, _p, _i, _i, _p]),
     'tamgcn_bn_bwd_finalize_multi': (_i, [C.POINTER(BnBwdDesc), _i, _p]),
     'tamgcn_tmean': (_i, [_SP, _i, _i, _i, _i, _p, _p]),
     'tamgcn_ctrgc_build_e': (_i, [C.POINTER(CtrgcDesc), _p, _p]),
@@ -168,7 +169,7 @@ class TamgcnLibraryError(RuntimeError):
 
 
 _lib = None
-ABI_VERSION = 400          # include/tamgcn.h TAMGCN_VERSION this binding's structs and signatures were written for
+ABI_VERSION = 401          # include/tamgcn.h TAMGCN_VERSION this binding's structs and signatures were written for
 
 
 def load():

@@ -182,6 +182,29 @@ extern "C" int tamgcn_bn_fwd_finalize(const float* part, int part_ctot, int part
     return 0;
 }
 
+// The two-source prologue of unit_gcn's offset_conv input (models/ctrgcn.py:256-258, diff = down(x) - bn(y)) as ONE launch
+// instead of torch's neg / sub / ones_like / stack (42 tiny launches per training step):  out [3][C] =
+//   mode 0 (down = conv + bn):  (cd[0], -cy[0], cd[2] - cy[2])      mode 1 (down = identity):  (1, -cy[0], -cy[2])
+//   mode 2 (no residual):       (-cy[0], 0, -cy[2])
+__global__ void coef_diff_kernel(const float* cd, const float* cy, float* out, int C, int mode) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float y0 = cy[c], y2 = cy[2 * C + c];
+    float r0, r1, r2;
+    if (mode == 0) { r0 = cd[c]; r1 = -y0; r2 = cd[2 * C + c] - y2; }
+    else if (mode == 1) { r0 = 1.f; r1 = -y0; r2 = -y2; }
+    else { r0 = -y0; r1 = 0.f; r2 = -y2; }
+    out[c] = r0; out[C + c] = r1; out[2 * C + c] = r2;
+}
+
+extern "C" int tamgcn_coef_diff(const float* coef_d, const float* coef_y, float* out, int C, int mode, void* stream) {
+    TG_CHECK(coef_y && out && C > 0 && mode >= 0 && mode <= 2 && (mode != 0 || coef_d), "tamgcn_coef_diff: bad args");
+    hipLaunchKernelGGL(coef_diff_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, coef_d, coef_y, out, C, mode);
+    tamgcn_note_kernel("coef_diff_kernel");
+    TG_LAUNCH_CHECK("tamgcn_coef_diff");
+    return 0;
+}
+
 extern "C" int tamgcn_bn_bwd_finalize(const float* part, int part_ctot, int part_coff, int nparts, double count,
                                       const float* gamma, const float* save, int save_ctot, int save_coff,
                                       int training, float* dgamma, float* dbeta, float* dbias_conv,

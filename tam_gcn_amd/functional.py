@@ -269,12 +269,7 @@ def gcn_forward(x, P, training, save):
             cy, sy = _eval_coefs([(P.bn, 0)], Cout, x)
             co, so = _eval_coefs([(P.bno, 0)], Cout, x)
             cd, sd_ = _eval_coefs([(P.bnd, 0)], Cout, x) if P.mode == 'conv' else (None, None)
-            if P.mode == 'conv':
-                cdiff = torch.stack((cd[0], -cy[0], cd[2] - cy[2]))
-            elif P.mode == 'identity':
-                cdiff = torch.stack((torch.ones_like(cy[0]), -cy[0], -cy[2]))
-            else:
-                cdiff = torch.stack((-cy[0], torch.zeros_like(cy[0]), -cy[2]))
+            cdiff = ops.coef_diff(cd, cy, {'conv': 0, 'identity': 1}.get(P.mode, 2))
             return dict(y=(cy, sy), o=(co, so), d=(cd, sd_), diff=cdiff)
         ev = _eval_cached(P.bn.m, 'unit_gcn', bns, build)
     if P.mode == 'conv':                               # independent of the CTRGC chain: side stream
@@ -308,15 +303,15 @@ def gcn_forward(x, P, training, save):
         bb.flush()
     if P.mode == 'conv':
         res = S(d_pre, coef=coef_d)
-        coef_diff = ev['diff'] if ev is not None else torch.stack((coef_d[0], -coef_y[0], coef_d[2] - coef_y[2]))
+        coef_diff = ev['diff'] if ev is not None else ops.coef_diff(coef_d, coef_y, 0)
         diff = S(d_pre, y_pre, coef_diff)
     elif P.mode == 'identity':
         res = xs
-        coef_diff = ev['diff'] if ev is not None else torch.stack((torch.ones_like(coef_y[0]), -coef_y[0], -coef_y[2]))
+        coef_diff = ev['diff'] if ev is not None else ops.coef_diff(None, coef_y, 1)
         diff = S(x, y_pre, coef_diff)
     else:                                                                  # residual=False: down(x) = 0
         res = None
-        coef_diff = ev['diff'] if ev is not None else torch.stack((-coef_y[0], torch.zeros_like(coef_y[0]), -coef_y[2]))
+        coef_diff = ev['diff'] if ev is not None else ops.coef_diff(None, coef_y, 2)
         diff = S(y_pre, None, coef_diff)
     o_pre, opart = ops.conv(diff, K=Cout, w=P.Wo, bias=P.bo, M=Cout, stats=training)
     if ev is not None:

@@ -377,6 +377,14 @@ def _reduce_piece(part, nsplit, stride, off, count, scale, out, accumulate=False
 
 
 # ---------------------------------------------------------------------------
+def coef_diff(coef_d, coef_y, mode):
+    """[3][C] prologue coefficients of diff = down(x) - bn(y) in one launch (include/tamgcn.h: tamgcn_coef_diff)."""
+    out = torch.empty_like(coef_y)
+    _lib.check(_lib_().tamgcn_coef_diff(_ptr(coef_d), _ptr(coef_y), _ptr(out), coef_y.shape[1], mode, _stream()), 'tamgcn_coef_diff')
+    return out
+
+
+# ---------------------------------------------------------------------------
 def bn_fwd_finalize(part, part_coff, count, gamma, beta, rmean, rvar, nbt, momentum, eps, training,
                     coef, save, coff, C_):
     lib = _lib_()

@@ -29,7 +29,7 @@ def test_library_builds_and_exports_every_declared_symbol():
 def test_version_and_error_text_callable_without_gpu():
     from tam_gcn_amd import _lib
     lib = _lib.load()
-    assert lib.tamgcn_version() == _lib.ABI_VERSION == 400
+    assert lib.tamgcn_version() == _lib.ABI_VERSION == 401
     # argument validation happens before any launch => usable on a CPU-only box
     assert lib.tamgcn_reduce_sum(None, 0, 0, 0, 1.0, 0, None, None) < 0
     assert b'tamgcn_reduce_sum' in lib.tamgcn_last_error()
