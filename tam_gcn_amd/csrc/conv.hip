@@ -802,13 +802,35 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void conv1x1_glds_kernel(
             if constexpr (NSRC == 2) fb2[cc] = smem[sb + vb[cc] + BK * G_PBMAX];
         }
     };
+    // the prologue in packed fp32 (v_pk_fma_f32: two elements per instruction -- a VALU instruction costs an fp32 MFMA slot here),
+    // the ReLU only where the source has one (same operations in the same order as the scalar form: bit-identical)
+    typedef float pf2 __attribute__((ext_vector_type(2)));
+    const bool relu = a.src.act == 1;
     auto pro = [&](int set) {
+        if constexpr (!PRO) {
 #pragma unroll
-        for (int cc = 0; cc < G_CWT; ++cc) {
-            if constexpr (!PRO) bvs[set][cc] = fb[cc];
-            else if (TG_KO & 2) bvs[set][cc] = fb[cc] + (NSRC == 2 ? fb2[cc] : 0.f);
-            else if constexpr (NSRC == 2) bvs[set][cc] = fmaxf(fmaf(fc[0], fb[cc], fmaf(fc[1], fb2[cc], fc[2])), lo);
-            else bvs[set][cc] = fmaxf(fmaf(fc[0], fb[cc], fc[2]), lo);
+            for (int cc = 0; cc < G_CWT; ++cc) bvs[set][cc] = fb[cc];
+        } else if (TG_KO & 2) {
+#pragma unroll
+            for (int cc = 0; cc < G_CWT; ++cc) bvs[set][cc] = fb[cc] + (NSRC == 2 ? fb2[cc] : 0.f);
+        } else {
+            const pf2 C1 = {fc[0], fc[0]}, C2 = {fc[1], fc[1]}, C0 = {fc[2], fc[2]};
+#pragma unroll
+            for (int cc = 0; cc + 1 < G_CWT; cc += 2) {
+                pf2 v = {fb[cc], fb[cc + 1]};
+                if constexpr (NSRC == 2) v = __builtin_elementwise_fma(C1, v, __builtin_elementwise_fma(C2, (pf2){fb2[cc], fb2[cc + 1]}, C0));
+                else v = __builtin_elementwise_fma(C1, v, C0);
+                bvs[set][cc] = v[0]; bvs[set][cc + 1] = v[1];
+            }
+            if constexpr (G_CWT & 1) {
+                constexpr int cc = G_CWT - 1;
+                if constexpr (NSRC == 2) bvs[set][cc] = fmaf(fc[0], fb[cc], fmaf(fc[1], fb2[cc], fc[2]));
+                else bvs[set][cc] = fmaf(fc[0], fb[cc], fc[2]);
+            }
+            if (relu) {
+#pragma unroll
+                for (int cc = 0; cc < G_CWT; ++cc) asm("v_max_f32 %0, 0, %0" : "+v"(bvs[set][cc]));   // ONE instruction (fmaxf(x, 0.f) and fmed3 both come with a canonicalising v_max)
+            }
         }
     };
     // Pinning the order.  Neither sched_barrier nor sched_group_barrier holds it (instruction selection lets the unchained
