@@ -19,7 +19,7 @@ if len(sys.argv) > 1 and sys.argv[1] == 'arm':
         for _ in range(reps): f()
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps * 1e3
-    N, V = 256, 20
+    N, V = int(os.environ.get('BENCH_N', 256)), 20
     # name, K, M, T, two sources, stats (forward) / data gradient with adds + broadcast
     for nm, K, M, T, two, kind in [('fwd 64->64 stats', 64, 64, 64, False, 'f'), ('fwd 64->48 stats', 64, 48, 64, False, 'f'),
                                    ('fwd 128->128 stats', 128, 128, 32, False, 'f'), ('fwd 256->256 stats', 256, 256, 16, False, 'f'),
