@@ -190,10 +190,14 @@ __global__ void coef_diff_kernel(const float* cd, const float* cy, float* out, i
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const float y0 = cy[c], y2 = cy[2 * C + c];
-    float r0, r1, r2;
-    if (mode == 0) { r0 = cd[c]; r1 = -y0; r2 = cd[2 * C + c] - y2; }
-    else if (mode == 1) { r0 = 1.f; r1 = -y0; r2 = -y2; }
-    else { r0 = -y0; r1 = 0.f; r2 = -y2; }
+    // (written with selects: hipcc 7.2 compiled the if / else-if / else form of this into code whose third branch stored
+    // r0 = 1 and an unset register for r2 -- found by tests/test_gpu_primitives.py::test_coef_diff_kernel; mode 2 has no caller
+    // in the CTR-GCN models, whose unit_gcn always carries a residual)
+    const bool m0 = mode == 0, m1 = mode == 1;
+    const float d0 = m0 ? cd[c] : 0.f, d2 = m0 ? cd[2 * C + c] : 0.f;
+    const float r0 = m0 ? d0 : (m1 ? 1.f : -y0);
+    const float r1 = (m0 || m1) ? -y0 : 0.f;
+    const float r2 = m0 ? d2 - y2 : -y2;
     out[c] = r0; out[C + c] = r1; out[2 * C + c] = r2;
 }
 

@@ -130,6 +130,39 @@ def test_pointwise_dma_gemms_with_prologue(shape):
     close(dx.double(), dxr, 1e-4, 2e-4 * float(dxr.abs().max()), 'conv bwd-data (DMA)')
 
 
+@pytest.mark.parametrize('shape', [(2, 768, 256, 16, 20, 1), (3, 384, 128, 16, 20, 0), (2, 192, 64, 24, 25, 1), (2, 400, 96, 12, 25, 0), (1, 64, 16, 16, 20, 1)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_plain_source_gemm_without_prologue_table(shape):
+    """Round 4: a plain source tensor (no coefficients, second source or ReLU) takes the GEMM instantiation WITHOUT the [3][K]
+    coefficient table (two workgroups per CU also at K >= 384) -- the dx <- dx3 GEMMs (reference models/ctrgcn.py:252-254 backward).
+    Both weight layouts, broadcast term + two residual adds, V = 20 / 25, K up to 768 and not a multiple of 64; fp64 reference."""
+    from tam_gcn_amd import ops
+    from tam_gcn_amd.ops import S
+    N, K, M, T, V, wmode = shape
+    d = dev()
+    x = rnd((N, K + 8, T, V), 1)
+    w = (rnd((K, M, 1, 1), 2) if wmode else rnd((M, K, 1, 1), 2)) * 0.1
+    a1, a2, bc = rnd((N, M, T, V), 3), rnd((N, M, T, V), 4), rnd((M, N, V), 5)
+    t = lambda z: z.to(d)
+    y, _ = ops.conv(S(t(x), coff=8), K=K, w=t(w), bias=None, M=M, wmode=wmode, bcast=t(bc), bcast_scale=0.25, add1=t(a1), add2=t(a2))
+    assert ops._lib_().tamgcn_last_kernel().decode().startswith('conv1x1_glds_kernel<1, 16, false'), ops._lib_().tamgcn_last_kernel()
+    wm = w[:, :, 0, 0].double()
+    ref = torch.einsum('km,nktv->nmtv' if wmode else 'mk,nktv->nmtv', wm, x[:, 8:].double())
+    ref = ref + 0.25 * bc.double().permute(1, 0, 2)[:, :, None, :] + a1.double() + a2.double()
+    close(y.double(), ref, 1e-4, 2e-4 * float(ref.abs().max()), 'plain-source GEMM')
+
+
+def test_coef_diff_kernel():
+    """tamgcn_coef_diff: the two-source prologue coefficients of unit_gcn's offset_conv input (reference models/ctrgcn.py:256-258,
+    diff = down(x) - bn(y)) -- bit-identical to the torch expressions it replaced, all three residual modes."""
+    from tam_gcn_amd import ops
+    d = dev()
+    cd, cy = rnd((3, 72), 1).to(d), rnd((3, 72), 2).to(d)
+    assert torch.equal(ops.coef_diff(cd, cy, 0), torch.stack((cd[0], -cy[0], cd[2] - cy[2])))
+    assert torch.equal(ops.coef_diff(None, cy, 1), torch.stack((torch.ones_like(cy[0]), -cy[0], -cy[2])))
+    assert torch.equal(ops.coef_diff(None, cy, 2), torch.stack((-cy[0], torch.zeros_like(cy[0]), -cy[2])))
+
+
 def test_conv_prologue_slices_mask_aux():
     from tam_gcn_amd import ops
     from tam_gcn_amd.ops import S
