@@ -14,6 +14,7 @@ MODULE_CASES = [
     ('gcn_64_64',         'unit_gcn', dict(in_channels=64, out_channels=64),   (2, 64, 8, 20),  12),
     ('gcn_64_128',        'unit_gcn', dict(in_channels=64, out_channels=128),  (2, 64, 6, 20),  12),
     ('gcn_128_128_v25',   'unit_gcn', dict(in_channels=128, out_channels=128), (1, 128, 5, 25), 12),
+    ('gcn_64_64_nores',   'unit_gcn', dict(in_channels=64, out_channels=64, residual=False), (2, 64, 7, 20), 12),   # down(x) = 0 (:217-218)
     # TemporalConv (:52-69)
     ('tconv_16_k5_s1_d1', 'TemporalConv', dict(in_channels=16, out_channels=16, kernel_size=5, stride=1, dilation=1), (2, 16, 13, 20), 13),
     ('tconv_16_k5_s2_d2', 'TemporalConv', dict(in_channels=16, out_channels=16, kernel_size=5, stride=2, dilation=2), (2, 16, 13, 20), 13),

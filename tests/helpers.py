@@ -38,6 +38,8 @@ def oracle_run(kind, kw, sd, x, training, extras=None):
         A, alpha = extras
         return O.ctrgc(x, sd, 'm', A, alpha)
     if kind == 'unit_gcn':
+        if not kw.get('residual', True):
+            return O.unit_gcn_noresidual(x, sd, 'm', training)
         return O.unit_gcn(x, sd, 'm', training)
     if kind == 'TemporalConv':
         return O.temporal_conv(x, sd, 'm', kw['kernel_size'], kw.get('stride', 1), kw.get('dilation', 1), training)
