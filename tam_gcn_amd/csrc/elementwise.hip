@@ -58,8 +58,9 @@ __device__ __forceinline__ float4 row_val4(const RowSrc& r, int i4) {
     if (r.act == 1) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
     return o;
 }
-// rows are 16-byte aligned iff L % 4 == 0 (allocations are 256-byte aligned)
-#define EW_VEC(L) (((L) & 3) == 0)
+// Every row-wise kernel below walks a row as L / 4 groups of four floats plus a scalar tail of L % 4 elements.  Rows are 16-byte
+// aligned only if L % 4 == 0; gfx950 takes dword-aligned 16-byte accesses at full rate (tools/probes/unaligned_probe.hip), and the
+// scalar loops NTU's T = 150 / 75 layers (L = 3750 / 1875) used to take ran at under half the streaming rate.
 
 // ---- unit_gcn tail -------------------------------------------------------
 __global__ __launch_bounds__(EW_THREADS) void gcn_tail_fwd_kernel(RowGeo geo, SrcDev y, SrcDev o, SrcDev res, int has_res,
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(EW_THREADS) void gcn_tail_fwd_kernel(RowGeo geo, Sr
     RowSrc rr = ry;
     if (has_res) rr = row_src(res, ((long long)n * res.ctot + res.coff + c) * L, res.coff + c);
     float* gp = g + ((long long)n * C + c) * L;
-    if (EW_VEC(L)) {
+    {                                      // groups of four floats (rows need only be 4-byte aligned: V = 25), then the row's tail
         for (int i = li; i < (L >> 2); i += geo.tpr) {
             float4 a = row_val4(ry, i), b = row_val4(ro, i);
             float4 r = has_res ? row_val4(rr, i) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -81,8 +82,9 @@ __global__ __launch_bounds__(EW_THREADS) void gcn_tail_fwd_kernel(RowGeo geo, Sr
             v.z = fmaxf(a.z + tanhf(b.z) + r.z, 0.f); v.w = fmaxf(a.w + tanhf(b.w) + r.w, 0.f);
             reinterpret_cast<float4*>(gp)[i] = v;
         }
-    } else {
-        for (int i = li; i < L; i += geo.tpr) {
+    }
+    {
+        for (int i = (L & ~3) + li; i < L; i += geo.tpr) {
             float v = row_val(ry, i) + tanhf(row_val(ro, i));
             if (has_res) v += row_val(rr, i);
             gp[i] = fmaxf(v, 0.f);
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(EW_THREADS) void gcn_tail_bwd_kernel(RowGeo geo, co
     const RowSrc ro = row_src(o, bo, o.coff + c);
     float s[2] = {0.f, 0.f};
     const float mu = o_save[o.coff + c];
-    if (EW_VEC(L)) {
+    {                                      // groups of four floats (rows need only be 4-byte aligned: V = 25), then the row's tail
         for (int i = li; i < (L >> 2); i += geo.tpr) {
             float4 gg = reinterpret_cast<const float4*>(g + b)[i], dd = reinterpret_cast<const float4*>(dg + b)[i];
             float4 ob = row_val4(ro, i), op = reinterpret_cast<const float4*>(o.x1 + bo)[i];
@@ -115,8 +117,9 @@ __global__ __launch_bounds__(EW_THREADS) void gcn_tail_bwd_kernel(RowGeo geo, co
             s[0] += (z.x + z.y) + (z.z + z.w);
             s[1] = fmaf(z.x, op.x - mu, fmaf(z.y, op.y - mu, fmaf(z.z, op.z - mu, fmaf(z.w, op.w - mu, s[1]))));
         }
-    } else {
-        for (int i = li; i < L; i += geo.tpr) {
+    }
+    {
+        for (int i = (L & ~3) + li; i < L; i += geo.tpr) {
             float d = g[b + i] > 0.f ? dg[b + i] : 0.f;
             float off = tanhf(row_val(ro, i));
             float dz = d * (1.f - off * off);
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(EW_THREADS) void gcn_mid_bwd_kernel(RowGeo geo, con
     const long long b = ((long long)n * C + c) * L;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     const float muy = y_save[c], mur = r_pre ? r_save[c] : 0.f;
-    if (EW_VEC(L)) {
+    {                                      // groups of four floats (rows need only be 4-byte aligned: V = 25), then the row's tail
         for (int i = li; i < (L >> 2); i += geo.tpr) {
             float4 d = reinterpret_cast<const float4*>(dsum + b)[i], dd = reinterpret_cast<const float4*>(ddiff + b)[i];
             float4 yp = reinterpret_cast<const float4*>(y_pre + b)[i];
@@ -154,8 +157,9 @@ __global__ __launch_bounds__(EW_THREADS) void gcn_mid_bwd_kernel(RowGeo geo, con
                 s[3] = fmaf(r.x, rp.x - mur, fmaf(r.y, rp.y - mur, fmaf(r.z, rp.z - mur, fmaf(r.w, rp.w - mur, s[3]))));
             }
         }
-    } else {
-        for (int i = li; i < L; i += geo.tpr) {
+    }
+    {
+        for (int i = (L & ~3) + li; i < L; i += geo.tpr) {
             float d = dsum[b + i], dd = ddiff[b + i];
             float a = d - dd, r = d + dd;
             dyb[b + i] = a;
@@ -353,6 +357,78 @@ __global__ __launch_bounds__(EW_THREADS) void maxpool_bwd_vec_kernel(RowGeo geo,
     if (part) row_store_sums(s, 2, part, dctot, N, dcoff + c, n, geo, li, rowok);
 }
 
+// Stride 1, ANY joint count (NTU's V = 25: 6.8 of config 3's 176 ms went through the staged kernel): the same decisions on
+// groups of four consecutive FLAT positions p = t*V + v of a (n, c) row of L = T*V floats.  The source rows th-2 .. th+2 of
+// an element are the positions p + (k-2)*V and the gradient rows of its windows p + (w-1)*V -- the same shift for all four
+// elements of a group -- and "row inside the tensor" is 0 <= position < L: no frame index, no division.  A shifted group that
+// sticks out of the row (two per row and shift) is fetched element by element; rows need only be 4-byte aligned.
+__global__ __launch_bounds__(EW_THREADS) void maxpool_bwd_flat_kernel(RowGeo geo, SrcDev gy, SrcDev src, const float* src_save, int C, int T, int V,
+                                                                      float* d, int dctot, int dcoff, int N, float* part) {
+    int c, n, li;
+    const bool rowok = row_coords(geo, C, c, n, li);
+    const int L = T * V;
+    const int ngrp = rowok ? (L + 3) >> 2 : 0;
+    const float* sp = src.x1 + ((long long)n * src.ctot + src.coff + c) * L;
+    const float* g1p = gy.x1 + ((long long)n * gy.ctot + gy.coff + c) * L;
+    const float* g2p = (gy.x2 ? gy.x2 : gy.x1) + ((long long)n * gy.ctot + gy.coff + c) * L;
+    float* dp = d + ((long long)n * dctot + dcoff + c) * L;
+    const int sch = src.coff + c, gch = gy.coff + c;
+    const float sc1 = src.coef ? src.coef[sch] : 1.f, sc0 = src.coef ? src.coef[2 * src.ctot + sch] : 0.f;
+    const float gc1 = gy.coef ? gy.coef[gch] : 1.f, gc2 = (gy.coef && gy.x2) ? gy.coef[gy.ctot + gch] : 0.f,
+                gc0 = gy.coef ? gy.coef[2 * gy.ctot + gch] : 0.f;
+    const float mu = src_save[sch];
+    auto ld4 = [&](const float* base, int start, float (&o)[4]) {
+        if (start >= 0 && start + 4 <= L) {
+            const float4 t = *reinterpret_cast<const float4*>(base + start);
+            o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (start + e >= 0 && start + e < L) ? base[start + e] : 0.f;
+        }
+    };
+    float s[2] = {0.f, 0.f};
+    for (int g = li; g < ngrp; g += geo.tpr) {
+        const int p = g << 2;
+        float xr[5][4], ga[3][4], gb[3][4];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) ld4(sp, p + (k - 2) * V, xr[k]);
+#pragma unroll
+        for (int w = 0; w < 3; ++w) { ld4(g1p, p + (w - 1) * V, ga[w]); ld4(g2p, p + (w - 1) * V, gb[w]); }
+        float xa[5][4];
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int q = p + e + (k - 2) * V;
+                float val = fmaf(sc1, xr[k][e], sc0);
+                if (src.act == 1) val = fmaxf(val, 0.f);
+                xa[k][e] = (q >= 0 && q < L) ? val : -INFINITY;        // outside the tensor: never a candidate
+            }
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int q = p + e + (w - 1) * V;                     // the window's centre position
+                const float x0 = xa[2][e];
+                bool win;                                              // as in maxpool_bwd_vec_kernel<1>: ctr = w + 1
+                if (w == 0) win = xa[0][e] < x0 && xa[1][e] < x0;
+                else if (w == 1) win = xa[1][e] < x0 && !(xa[3][e] > x0);
+                else win = !(xa[3][e] > x0) && !(xa[4][e] > x0);
+                if (q >= 0 && q < L && win && x0 > 0.f) o[e] += fmaf(gc1, ga[w][e], fmaf(gc2, gb[w][e], gc0));
+            }
+        if (p + 4 <= L) *reinterpret_cast<float4*>(dp + p) = make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (p + e < L) {
+                if (p + 4 > L) dp[p + e] = o[e];
+                s[0] += o[e];
+                s[1] = fmaf(o[e], xr[2][e] - mu, s[1]);
+            }
+    }
+    if (part) row_store_sums(s, 2, part, dctot, N, dcoff + c, n, geo, li, rowok);
+}
+
 // ---- residual add (+ReLU) -------------------------------------------------
 // rowmean != nullptr: also the mean of every output row (the last block's contribution to the model head's pooling,
 // models/ctrgcn.py:343-345, taken while the row is in registers)
@@ -367,7 +443,7 @@ __global__ __launch_bounds__(EW_THREADS) void add_act_fwd_kernel(RowGeo geo, Src
     float* op = out + ((long long)n * C + c) * L;
     const int Lrow = L;
     float acc = 0.f;
-    if (EW_VEC(L)) {
+    {                                      // groups of four floats (rows need only be 4-byte aligned: V = 25), then the row's tail
         for (int i = li; i < (L >> 2); i += geo.tpr) {
             float4 v = row_val4(ra, i);
             if (has_res) { float4 r = row_val4(rr, i); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
@@ -375,8 +451,9 @@ __global__ __launch_bounds__(EW_THREADS) void add_act_fwd_kernel(RowGeo geo, Src
             reinterpret_cast<float4*>(op)[i] = v;
             acc += (v.x + v.y) + (v.z + v.w);
         }
-    } else {
-        for (int i = li; i < L; i += geo.tpr) {
+    }
+    {
+        for (int i = (L & ~3) + li; i < L; i += geo.tpr) {
             float v = row_val(ra, i);
             if (has_res) v += row_val(rr, i);
             v = relu ? fmaxf(v, 0.f) : v;
@@ -400,7 +477,7 @@ __global__ __launch_bounds__(EW_THREADS) void add_act_bwd_kernel(RowGeo geo, con
     const long long b = ((long long)n * C + c) * L;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     const float mua = a_pre ? a_save[c] : 0.f, mur = r_pre ? r_save[c] : 0.f;
-    if (EW_VEC(L)) {
+    {                                      // groups of four floats (rows need only be 4-byte aligned: V = 25), then the row's tail
         for (int i = li; i < (L >> 2); i += geo.tpr) {
             float4 d = reinterpret_cast<const float4*>(dout + b)[i];
             if (relu) {
@@ -422,8 +499,9 @@ __global__ __launch_bounds__(EW_THREADS) void add_act_bwd_kernel(RowGeo geo, con
                 s[3] = fmaf(d.x, p.x - mur, fmaf(d.y, p.y - mur, fmaf(d.z, p.z - mur, fmaf(d.w, p.w - mur, s[3]))));
             }
         }
-    } else {
-        for (int i = li; i < L; i += geo.tpr) {
+    }
+    {
+        for (int i = (L & ~3) + li; i < L; i += geo.tpr) {
             float d = dout[b + i];
             if (relu && !(out[b + i] > 0.f)) d = 0.f;
             if (dz) dz[b + i] = d;
@@ -594,6 +672,13 @@ extern "C" int tamgcn_maxpool_bwd(const tamgcn_src* gy, const tamgcn_src* src, c
             hipLaunchKernelGGL(maxpool_bwd_vec_kernel<2>, row_grid(geo), dim3(EW_THREADS), 0, (hipStream_t)stream,
                                geo, make_src(*gy), make_src(*src), src_save, C, T_in, T_out, V, d, dctot, dcoff, N, part);
         tamgcn_note_kernel("maxpool_bwd_vec_kernel<%d>", stride);
+        TG_LAUNCH_CHECK("tamgcn_maxpool_bwd");
+        return 0;
+    }
+    if (vec_env && stride == 1 && !src->x2 && T_out == T_in && (long long)T_in * V < (1LL << 30)) {
+        hipLaunchKernelGGL(maxpool_bwd_flat_kernel, row_grid(geo), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                           geo, make_src(*gy), make_src(*src), src_save, C, T_in, V, d, dctot, dcoff, N, part);
+        tamgcn_note_kernel("maxpool_bwd_flat_kernel");
         TG_LAUNCH_CHECK("tamgcn_maxpool_bwd");
         return 0;
     }

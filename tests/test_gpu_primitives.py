@@ -682,10 +682,12 @@ def test_de_tail_r16_bit_identical_beside_other_streams_in_a_graph():
                 assert torch.equal(a_, b_), f'replay {rep}, problem {i}: {nm} differs by {float((a_ - b_).abs().max()):.3e}'
 
 
-@pytest.mark.parametrize('shape', [(2, 16, 13, 20, 1), (3, 32, 12, 20, 2), (2, 16, 7, 20, 2), (2, 64, 5, 64, 1), (1, 16, 1, 20, 1), (2, 16, 2, 20, 2)],
+@pytest.mark.parametrize('shape', [(2, 16, 13, 20, 1), (3, 32, 12, 20, 2), (2, 16, 7, 20, 2), (2, 64, 5, 64, 1), (1, 16, 1, 20, 1), (2, 16, 2, 20, 2),
+                                   (2, 16, 13, 25, 1), (3, 8, 6, 25, 1), (2, 8, 3, 25, 1), (1, 8, 1, 25, 1), (2, 8, 2, 25, 1), (2, 8, 5, 7, 1), (2, 8, 9, 3, 1)],
                          ids=lambda s: 'x'.join(map(str, s)))
 def test_maxpool_bwd_vector_kernel(shape):
-    """The LDS-free max-pool gradient (V % 4 == 0): two-source gradient prologue, channel slices of wider tensors, ragged and
+    """The LDS-free max-pool gradients (V % 4 == 0: groups of four joints of a frame, both strides; any V at stride 1: groups of
+    four flat positions of a row -- NTU's 25 joints, rows whose length is not a multiple of four): two-source gradient prologue, channel slices of wider tensors, ragged and
     tiny T, both strides, exact ties between window candidates (zeros behind the ReLU and planted equal positives: aten routes
     the gradient to the FIRST maximum) -- against autograd in fp64."""
     from tam_gcn_amd import ops
@@ -708,7 +710,7 @@ def test_maxpool_bwd_vector_kernel(shape):
     t = lambda z: z.to(d)
     bp = ops.maxpool_bwd(S(t(g1), t(g2), t(cg), coff=4), S(t(h), None, t(ch), coff=8, act=1), t(mu), C_, s, dd, 8)
     torch.cuda.synchronize()
-    assert 'vec' in ops._lib_().tamgcn_last_kernel().decode()
+    assert ('vec' if V % 4 == 0 else 'flat') in ops._lib_().tamgcn_last_kernel().decode()
     got = dd[:, 8:].double().cpu()
     assert float((got - hb.grad).abs().max()) <= 2e-6 * (float(hb.grad.abs().max()) + 1e-6)
     assert float((dd[:, :8] - 5).abs().max()) == 0
