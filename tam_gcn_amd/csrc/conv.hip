@@ -653,6 +653,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void conv1x1_glds_kernel(
 
     // ---- per-lane DMA descriptors (the same for every chunk)
     const int NQ = (LB + 63) >> 6;                                // 1 KB pieces per 4-row group
+    const int ls = a.lstride;                                     // frame stride of the source (1; 2: the strided 1x1 convs, host-checked)
+    const float rV_ = 1.0f / (float)V;
     const int NI1 = (BK / 4) * NQ;                                // pieces per source and chunk
     int b_rel[MAXB], b_dst[MAXB];                                 // source offset (floats), LDS offset of the piece (floats)
     bool b_ok[MAXB], b_on[MAXB];
@@ -669,13 +671,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void conv1x1_glds_kernel(
         int col = off + (r & 1) * rot;                            // source column of this LDS slot
         if (col >= LB) col -= LB;
         b_ok[i] = idok && r < 4 && col < ncols;
-        b_rel[i] = (int)((grp * 4 + r) * TV) + col + src * 0x40000000;   // bit 30 tags the second source
+        // a 1x1 conv with a temporal stride (V % 4 == 0: a 16-byte slot never leaves its frame) reads every ls-th frame
+        const int scol = ls > 1 ? col + tc_like_div(col, rV_) * (ls - 1) * V : col;
+        b_rel[i] = (int)((grp * 4 + r) * TV) + scol + src * 0x40000000;   // bit 30 tags the second source
         b_dst[i] = src * (BK * G_PBMAX) + grp * 4 * LB + q * 256;
         b_on[i] = __ballot(b_ok[i]) != 0ull;                      // wave-uniform: the piece exists
         nissue += b_on[i] ? 1 : 0;
     }
-    const float* xb1 = a.src.x1 + ((long long)n * a.src.ctot + a.src.coff) * TV + (long long)t0 * V;
-    const float* xb2 = NSRC == 2 ? a.src.x2 + ((long long)n * a.src.ctot + a.src.coff) * TV + (long long)t0 * V : nullptr;
+    const float* xb1 = a.src.x1 + ((long long)n * a.src.ctot + a.src.coff) * TV + (long long)t0 * ls * V;
+    const float* xb2 = NSRC == 2 ? a.src.x2 + ((long long)n * a.src.ctot + a.src.coff) * TV + (long long)t0 * ls * V : nullptr;
     // A (weight) pieces.  wmode 1 (w[k][m], data gradient): one dword piece per k row, lane = channel, coalesced.
     // wmode 0 (w[m][k]): a row's BK taps are contiguous, so 64/BK*4.. lanes share a row: dwordx4 pieces of
     // (1024 / (4*BK)) rows, image [m][BK]; the 16-byte quads of a row are XOR-swizzled on the SOURCE address
@@ -1293,7 +1297,10 @@ extern "C" int tamgcn_conv(const tamgcn_conv_desc* d, void* stream) {
     dim3 grid(p.ntt, ceil_div(d->M, BM), d->N);
     // 1x1 stride-1 convs whose rows are plain contiguous column ranges go to the LDS-DMA GEMM
     const bool aligned16 = (((uintptr_t)d->src.x1 | (uintptr_t)(d->src.x2 ? d->src.x2 : d->src.x1) | (uintptr_t)d->w) & 15) == 0;
-    const bool glds = p.vec && p.flat && d->K % 16 == 0 && p.LB >= 64 && p.LB <= G_PBMAX && (p.LB & 3) == 0 &&
+    // ... and so do 1x1 convs with a temporal stride when V % 4 == 0 (round 4: they were 0.4 ms/step on the register-staged kernel)
+    const bool strided1x1 = d->KT == 1 && d->stride == 2 && d->up == 1 && d->pad == 0 && (d->V & 3) == 0 && d->T_out == (d->T_in - 1) / 2 + 1 &&
+                            p.lstride == 2 && p.TIN == p.BT && p.nsl == 1 && p.Vp == d->V && !d->mask && !d->aux;
+    const bool glds = p.vec && (p.flat || strided1x1) && d->K % 16 == 0 && p.LB >= 64 && p.LB <= G_PBMAX && (p.LB & 3) == 0 &&
                       aligned16 && (long long)d->K * d->T_in * d->V < (1LL << 30);
     // data gradients into >= 128 channels: 128-row tiles on the bf16 matrix cores, operands split in registers into a
     // two-term bf16 pair (linear prologue only: it folds into the weights); no moments

@@ -32,6 +32,9 @@ CONV_CASES = [
     (2, 32, 32, 12, 20, 5, 2, 2),
     (2, 16, 16, 13, 20, 5, 1, 2),
     (2, 64, 128, 13, 20, 1, 1, 2),
+    (3, 128, 256, 32, 20, 1, 1, 2),    # strided 1x1 on the LDS-DMA GEMM (round 4): one full 16-frame tile per clip
+    (2, 64, 64, 35, 20, 1, 1, 2),      # ... 18 output frames: a full tile and a 2-frame one
+    (2, 32, 48, 9, 64, 1, 1, 2),       # ... V = 64: 5 frames per tile
     (1, 70, 40, 9, 25, 1, 1, 1),
     (1, 16, 16, 12, 20, 9, 1, 1),
     (1, 12, 12, 11, 20, 3, 3, 1),
