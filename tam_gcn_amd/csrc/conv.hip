@@ -1711,7 +1711,9 @@ __global__ __launch_bounds__(W_NT, 2) void wgrad_glds_kernel(const WgradArgs a, 
         else { split = L / nt; tile = L - split * nt; }
     }
     const int k0 = (tile % ntk) * BKW, m0 = (tile / ntk) * BMW;
-    const long long cs = (long long)a.T_out * a.V;               // == T_in * V: channel-row stride of both operands
+    const long long cs = (long long)a.T_out * a.V;               // channel-row stride of gy (and of x at stride 1)
+    const long long csx = (long long)a.T_in * a.V;               // ... of x
+    const float rV = 1.0f / (float)a.V;
     // this tap's window: frames t with 0 <= t < T and 0 <= t + dlt < T
     const int dlt = a.KTG > 1 ? tap * a.dil - a.pad : 0;
     const int wlen = (a.T_out - (dlt < 0 ? -dlt : dlt)) * a.V;    // host: >= 2 * W_PC
@@ -1741,19 +1743,20 @@ __global__ __launch_bounds__(W_NT, 2) void wgrad_glds_kernel(const WgradArgs a, 
         const SrcDev& sd = isy ? a.gy : a.src;
         const int ch = (isy ? m0 : k0) + r;
         p_ok[i] = qok && ch < (isy ? a.M : a.K);
-        p_base[i] = (img == 0 ? sd.x1 : sd.x2) + (long long)(sd.coff + (p_ok[i] ? ch : 0)) * cs + pu * 4;
+        p_base[i] = (img == 0 ? sd.x1 : sd.x2) + (long long)(sd.coff + (p_ok[i] ? ch : 0)) * (isy ? cs : csx) + pu * 4;
         p_isy[i] = isy;
         p_dst[i] = row0 * W_PC;
         p_on[i] = __ballot(p_ok[i]) != 0ull;
         nissue += p_on[i] ? 1 : 0;
     }
-    const long long ystep = (long long)a.gy.ctot * cs, xstep = (long long)a.src.ctot * cs;
+    const long long ystep = (long long)a.gy.ctot * cs, xstep = (long long)a.src.ctot * csx;
     auto issue = [&](int c) {
         float* st = smem + (c % NST) * STG;
         const int gc = c_begin + c, nn = gc / cps, pc = gc - nn * cps;
         const int po = pc < cpf ? pc * W_PC : wlen - W_PC;        // the row's last, partial chunk: re-fetch the last 32
         const long long oy = (long long)nn * ystep + ylo + po;
-        const long long ox = (long long)nn * xstep + xlo + po;
+        // stride 2: this lane's slot starts at p0 = po + 4 pu of frame p0 / V; its x elements sit one frame further per frame
+        const long long ox = (long long)nn * xstep + xlo + po + (a.stride == 2 ? tc_like_div(po + pu * 4, rV) * a.V : 0);
 #pragma unroll
         for (int i = 0; i < MAXP; ++i) {
             if (p_on[i]) {
@@ -1998,7 +2001,10 @@ static bool wgrad_glds_plan(const tamgcn_wgrad_desc* d, int* wmt, int* wkt) {
     // =0 disables the tap form.
     const bool taps = d->KT > 1 && d->pad == d->dil * (d->KT - 1) / 2 && (d->dil * (d->KT - 1)) % 2 == 0 && tamgcn_wgrad_taps() &&
                       (d->M > 32 || d->K > 32 || (d->V % 4 != 0 && (d->M > 16 || d->K > 16)) || tamgcn_wgrad_taps() == 2);
-    bool glds = (taps || (d->KT == 1 && d->pad == 0)) && d->stride == 1 && d->T_in == d->T_out && al16 &&
+    // a 1x1 conv with temporal stride 2 (V % 4 == 0): gy rows are contiguous, the x slot of contraction index p = t*V + v
+    // sits at (2 t) V + v -- a per-lane source offset of the DMA piece, recomputed per chunk (round 4)
+    const bool strided = d->KT == 1 && d->pad == 0 && d->stride == 2 && (d->V & 3) == 0 && d->T_out == (d->T_in - 1) / 2 + 1;
+    bool glds = (taps || (d->KT == 1 && d->pad == 0)) && ((d->stride == 1 && d->T_in == d->T_out) || strided) && al16 &&
                 (long long)(d->T_out - d->pad) * d->V >= 2 * W_PC;
     if (!glds) return false;
     if (d->KT > 1) { *wmt = d->M <= 64 ? 2 : 4; *wkt = d->K <= 64 ? 2 : 4; }      // the 1x1 rule (units of 32)
