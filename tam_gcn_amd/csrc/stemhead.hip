@@ -37,19 +37,19 @@ __global__ __launch_bounds__(SH_NT) void stem_stats_kernel(const float* x, const
 // forward: out[(n*M+m), c, t, v] = c1[j] x + c0[j];  backward: dx[n,c,t,v,m] = c1[j] dout + c2[j] x + c0[j]
 __global__ __launch_bounds__(SH_NT) void stem_apply_kernel(const float* x, const float* dout, const float* coef,
                                                            int N, int C, int T, int V, int M, float* out, int backward) {
-    const long long total = (long long)N * C * T * V * M;
-    const int J = C * V * M;
-    for (long long e = (long long)blockIdx.x * SH_NT + threadIdx.x; e < total; e += (long long)gridDim.x * SH_NT) {
-        long long r = e;                                    // e indexes x: (n, c, t, v, m)
-        const int m = (int)(r % M); r /= M;
-        const int v = (int)(r % V); r /= V;
-        const int t = (int)(r % T); r /= T;
-        const int c = (int)(r % C);
-        const int n = (int)(r / C);
+    // one workgroup per (n, c) row of x: T*V*M contiguous floats.  (Round 4: the flat form of this kernel took an element index
+    // apart with five 64-bit divisions -- 118 us for 4 MB; per row everything is 32-bit and the frame index comes from a reciprocal.)
+    const int row = blockIdx.x, n = row / C, c = row - n * C;
+    const int TV = T * V, len = TV * M, J = C * V * M;
+    const float rV = 1.0f / (float)V;
+    const long long xb = (long long)row * len;
+    for (int i = threadIdx.x; i < len; i += SH_NT) {
+        const int tv = M == 1 ? i : (M == 2 ? i >> 1 : i / M), m = i - tv * M;
+        const int t = (int)(((float)tv + 0.5f) * rV), v = tv - t * V;          // tv < 2^20 (sh_dims_ok): exact
         const int j = (m * V + v) * C + c;
-        const long long o = ((((long long)n * M + m) * C + c) * T + t) * V + v;   // (n*M+m, c, t, v)
-        if (!backward) out[o] = fmaf(coef[j], x[e], coef[2 * J + j]);
-        else out[e] = fmaf(coef[j], dout[o], fmaf(coef[J + j], x[e], coef[2 * J + j]));
+        const long long o = (((long long)n * M + m) * C + c) * TV + tv;         // (n*M+m, c, t, v)
+        if (!backward) out[o] = fmaf(coef[j], x[xb + i], coef[2 * J + j]);
+        else out[xb + i] = fmaf(coef[j], dout[o], fmaf(coef[J + j], x[xb + i], coef[2 * J + j]));
     }
 }
 
@@ -223,10 +223,8 @@ extern "C" int tamgcn_stem_stats(const float* x, const float* dout, const float*
 extern "C" int tamgcn_stem_apply(const float* x, const float* dout, const float* coef, int N, int C, int T, int V, int M,
                                  float* out, void* stream) {
     TG_CHECK(x && coef && out && sh_dims_ok(N, C, T, V, M), "tamgcn_stem_apply: bad args");
-    const long long total = (long long)N * C * T * V * M;
-    long long blocks = (total + SH_NT - 1) / SH_NT;
-    if (blocks > 65535LL * 16) blocks = 65535LL * 16;
-    hipLaunchKernelGGL(stem_apply_kernel, dim3((unsigned)blocks), dim3(SH_NT), 0, (hipStream_t)stream, x, dout, coef, N, C, T, V, M, out,
+    TG_CHECK((long long)T * V * M < (1LL << 20) && (long long)N * C < (1LL << 31), "tamgcn_stem_apply: a row of T*V*M = %lld floats (limit 2^20)", (long long)T * V * M);
+    hipLaunchKernelGGL(stem_apply_kernel, dim3((unsigned)(N * C)), dim3(SH_NT), 0, (hipStream_t)stream, x, dout, coef, N, C, T, V, M, out,
                        dout ? 1 : 0);
     tamgcn_note_kernel("stem_apply_kernel");
     TG_LAUNCH_CHECK("tamgcn_stem_apply");
