@@ -92,8 +92,18 @@ __global__ __launch_bounds__(SH_NT) void fc_bwd_kernel(const float* dl, const fl
     if ((int)blockIdx.x < K) {
         const int k = blockIdx.x;
         for (int c = threadIdx.x; c < C; c += SH_NT) {
+            // 16 samples' operands are requested together (the loop was a chain of N dependent round trips: 77 us at N = 256);
+            // the additions keep their order
             float s = 0.f;
-            for (int n = 0; n < N; ++n) s = fmaf(dl[(long long)n * K + k], pooled[(long long)n * C + c], s);
+            int n = 0;
+            for (; n + 16 <= N; n += 16) {
+                float a[16], b[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { a[i] = dl[(long long)(n + i) * K + k]; b[i] = pooled[(long long)(n + i) * C + c]; }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s = fmaf(a[i], b[i], s);
+            }
+            for (; n < N; ++n) s = fmaf(dl[(long long)n * K + k], pooled[(long long)n * C + c], s);
             dW[(long long)k * C + c] = s;
         }
         if (threadIdx.x == 0) {
