@@ -2120,6 +2120,13 @@ __global__ __launch_bounds__(256) void reduce_multi_kernel(const ReduceMulti md)
     if (e < d.count) {
         const float* p = d.part + e;
         int k = w;
+        for (; k + 28 < d.nsplit; k += 32) {                      // eight independent loads in flight, summed as two groups of four
+            float a[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] = p[(long long)(k + 4 * i) * d.stride_s];
+            s += ((double)a[0] + (double)a[1]) + ((double)a[2] + (double)a[3]);
+            s += ((double)a[4] + (double)a[5]) + ((double)a[6] + (double)a[7]);
+        }
         for (; k + 12 < d.nsplit; k += 16) {                      // four independent loads in flight
             float a0 = p[(long long)k * d.stride_s], a1 = p[(long long)(k + 4) * d.stride_s];
             float a2 = p[(long long)(k + 8) * d.stride_s], a3 = p[(long long)(k + 12) * d.stride_s];
