@@ -223,8 +223,8 @@ def roofline_of(agg):
         else:
             r = dict(bound='hbm', achieved=bw / 1e9, peak=HBM_PEAK / 1e9, unit='GB/s', frac=bw / HBM_PEAK)
         r['nearest_roof'] = r['bound']
-        if max(bw / HBM_PEAK, fl / mpeak) < 0.5:
-            r['bound'] = 'issue'
+        # `bound` stays one of the contract's two values; a launch under half of both roofs is marked `limited_by: "issue"`
+        r['limited_by'] = 'issue' if max(bw / HBM_PEAK, fl / mpeak) < 0.5 else r['bound']
         r.update(common)
         return r
 
@@ -242,7 +242,7 @@ def roofline_of(agg):
         peak = BF16_MFMA_PEAK / 3.0 if ('split_kernel<2' in k or ', split,' in k) else F32_MFMA_PEAK
         fh, fm = v['bytes'] / sk / HBM_PEAK, v['flops'] / sk / peak
         near = 'mfma' if v['flops'] / peak > v['bytes'] / HBM_PEAK else 'hbm'
-        top.append(dict(kernel=k, ms=round(v['ms'], 3), launches=v['calls'], bound=near if max(fh, fm) >= 0.5 else 'issue', nearest_roof=near,
+        top.append(dict(kernel=k, ms=round(v['ms'], 3), launches=v['calls'], bound=near, limited_by=near if max(fh, fm) >= 0.5 else 'issue', nearest_roof=near,
                         hbm_frac=round(fh, 4), mfma_frac=round(fm, 4), mfma_peak_tflops=round(peak / 1e12, 1)))
     r['top3'] = top
     shares = {k: round(v['ms'], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])}
