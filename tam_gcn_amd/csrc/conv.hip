@@ -1418,15 +1418,30 @@ __device__ __forceinline__ void wg_fill(float* tile, int pitch, const float* cf,
             d[1] = make_float2(o.z, o.w);
         }
     } else {
-        for (int e = tid; e < rows * len; e += NTHREADS) {
-            int r = e / len, col = e - r * len;
-            int fr = f0 + col / V;
-            float o = 0.f;
-            if (r < nvalid && fr >= 0 && fr < T) {
-                long long g = nbase + (long long)(ch0 + r) * cs + (long long)f0 * V + col;
-                o = wg_apply(s.x1[g], s.x2 ? s.x2[g] : 0.f, cf[r], cf[rows + r], cf[2 * rows + r], s.act);
+        // V % 4 != 0 (NTU's 25 joints at stride 2): one float per step.  Round 4: the row / frame indices come from reciprocals
+        // (two integer divisions per element were ~50 VALU instructions) and four steps' loads are requested together.
+        const bool rcp_ok = len >= 4 && len <= 1024 && V >= 4 && rows * len < (1 << 20);
+        const float rlen = 1.0f / (float)len, rV = 1.0f / (float)V;
+        for (int e0 = tid; e0 < rows * len; e0 += 4 * NTHREADS) {
+            float v1[4], v2[4]; int rr[4], cc[4]; bool ok[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = e0 + i * NTHREADS;
+                const bool in = e < rows * len;
+                const int ee = in ? e : 0;
+                const int r = rcp_ok ? tc_like_div(ee, rlen) : ee / len, col = ee - r * len;
+                const int fr = f0 + (rcp_ok ? tc_like_div(col, rV) : col / V);
+                rr[i] = r; cc[i] = col;
+                ok[i] = in && r < nvalid && fr >= 0 && fr < T;
+                const long long g = nbase + (long long)(ch0 + (ok[i] ? r : 0)) * cs + (long long)f0 * V + (ok[i] ? col : 0);
+                v1[i] = ok[i] ? s.x1[g] : 0.f;
+                v2[i] = (ok[i] && s.x2) ? s.x2[g] : 0.f;
             }
-            tile[r * pitch + col] = o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = e0 + i * NTHREADS;
+                if (e < rows * len) tile[rr[i] * pitch + cc[i]] = ok[i] ? wg_apply(v1[i], v2[i], cf[rr[i]], cf[rows + rr[i]], cf[2 * rows + rr[i]], s.act) : 0.f;
+            }
         }
     }
 }
