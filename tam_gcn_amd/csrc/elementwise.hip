@@ -12,7 +12,9 @@ namespace {
 
 constexpr int EW_THREADS = 256;
 
-// row geometry of a launch: lanes per row (power of two, 16..64) -> rows per workgroup
+// row geometry of a launch: lanes per row (power of two, 16..256) -> rows per workgroup.  Round 4: long rows get the WHOLE workgroup
+// (the four waves walk one row together: 8.0 against 7.6 TB/s at 84 MB tensors, 5.0-5.6 against 4.8-5.4 at HBM-streaming sizes,
+// tools/probes/ew_layout_probe.hip); their row sums then meet in LDS.
 struct RowGeo { int tpr, rows; };               // rows = N * C
 __device__ __forceinline__ bool row_coords(const RowGeo& g, int C, int& c, int& n, int& li) {
     const int rpb = EW_THREADS / g.tpr;
@@ -23,11 +25,26 @@ __device__ __forceinline__ bool row_coords(const RowGeo& g, int C, int& c, int& 
     n = r / C; c = r - n * C;
     return ok;
 }
+// sum over the lanes of a row (every thread of the workgroup calls it; fixed order: lanes by xor-shuffle, then the row's waves in turn)
+__device__ __forceinline__ float row_sum(float v, const RowGeo& g) {
+    const int w = g.tpr < 64 ? g.tpr : 64;
+    for (int o = 1; o < w; o <<= 1) v += __shfl_xor(v, o);
+    if (g.tpr > 64) {                               // wave-uniform (kernel argument): the row spans tpr / 64 waves
+        __shared__ float red[EW_THREADS / 64];
+        const int wave = threadIdx.x >> 6, wpr = g.tpr >> 6, first = wave & ~(wpr - 1);
+        __syncthreads();                            // a previous call's reads of red
+        if ((threadIdx.x & 63) == 0) red[wave] = v;
+        __syncthreads();
+        float t = red[first];
+        for (int k = 1; k < wpr; ++k) t += red[first + k];
+        v = t;
+    }
+    return v;
+}
 __device__ __forceinline__ void row_store_sums(const float* vals, int nst, float* part, int C, int N, int c, int n,
                                                const RowGeo& g, int li, bool ok) {
     for (int s = 0; s < nst; ++s) {
-        float v = vals[s];
-        for (int o = 1; o < g.tpr; o <<= 1) v += __shfl_xor(v, o);
+        const float v = row_sum(vals[s], g);
         if (li == 0 && ok) part[((long long)s * C + c) * N + n] = v;
     }
 }
@@ -462,7 +479,7 @@ __global__ __launch_bounds__(EW_THREADS) void add_act_fwd_kernel(RowGeo geo, Src
         }
     }
     if (rowmean) {                          // uniform over the launch: every lane of the wave reaches the shuffles
-        for (int o = 1; o < geo.tpr; o <<= 1) acc += __shfl_xor(acc, o);
+        acc = row_sum(acc, geo);
         if (li == 0 && rowok) rowmean[(long long)n * C + c] = acc / (float)Lrow;
     }
 }
@@ -592,11 +609,16 @@ __global__ __launch_bounds__(EW_THREADS) void tmean_kernel(SrcDev src, int N, in
 
 static bool grid_ok(int N, int C) { return N > 0 && C > 0 && (long long)N * C < (1LL << 31); }
 
-// lanes per row: about five steps per lane (16-byte steps when the row length allows), 16..64
+// lanes per row: the whole workgroup for rows of >= 256 steps, half of it from 128, else about five steps per lane (16..64);
+// a step is 16 bytes where the kernel walks the row in groups of four floats
 static RowGeo row_geo(int N, int C, int L, bool vec_capable) {
-    const int steps = (vec_capable && (L & 3) == 0) ? L >> 2 : L;
+    const int steps = vec_capable ? (L + 3) >> 2 : L;
     int tpr = 16;
     while (tpr < 64 && tpr * 5 < steps) tpr <<= 1;
+    static int wide = -1;
+    if (wide < 0) { const char* e = getenv("TAMGCN_EW_WIDE"); wide = e ? atoi(e) : 1; }     // 0: at most one wave per row (A/B)
+    if (wide && steps >= 256) tpr = 256;
+    else if (wide && steps >= 128) tpr = 128;
     RowGeo g; g.tpr = tpr; g.rows = N * C;
     return g;
 }

@@ -65,6 +65,36 @@ __global__ __launch_bounds__(256) void rowchunk(const float* a, const float* b, 
         }
     }
 }
+// rowwg: one 256-thread workgroup per row, the four waves walk it together in 4 KB strides (loop kept, loads not batched)
+__global__ __launch_bounds__(256) void rowwg(const float* a, const float* b, const float* coef, float* out, int rows, int C, int L) {
+    const int row = blockIdx.x;
+    const int c = row % C;
+    const float c1 = coef[c], c0 = coef[2 * C + c];
+    const float4* ap = reinterpret_cast<const float4*>(a + (long long)row * L);
+    const float4* bp = reinterpret_cast<const float4*>(b + (long long)row * L);
+    float4* op = reinterpret_cast<float4*>(out + (long long)row * L);
+    for (int i = threadIdx.x; i < (L >> 2); i += 256) {
+        float4 x = ap[i], y = bp[i], v;
+        v.x = fmaxf(fmaf(c1, x.x, c0) + y.x, 0.f); v.y = fmaxf(fmaf(c1, x.y, c0) + y.y, 0.f);
+        v.z = fmaxf(fmaf(c1, x.z, c0) + y.z, 0.f); v.w = fmaxf(fmaf(c1, x.w, c0) + y.w, 0.f);
+        op[i] = v;
+    }
+}
+// rowwave: one 64-thread workgroup per row (the product's lane mapping, but a workgroup = one row)
+__global__ __launch_bounds__(64) void rowwave(const float* a, const float* b, const float* coef, float* out, int rows, int C, int L) {
+    const int row = blockIdx.x;
+    const int c = row % C;
+    const float c1 = coef[c], c0 = coef[2 * C + c];
+    const float4* ap = reinterpret_cast<const float4*>(a + (long long)row * L);
+    const float4* bp = reinterpret_cast<const float4*>(b + (long long)row * L);
+    float4* op = reinterpret_cast<float4*>(out + (long long)row * L);
+    for (int i = threadIdx.x; i < (L >> 2); i += 64) {
+        float4 x = ap[i], y = bp[i], v;
+        v.x = fmaxf(fmaf(c1, x.x, c0) + y.x, 0.f); v.y = fmaxf(fmaf(c1, x.y, c0) + y.y, 0.f);
+        v.z = fmaxf(fmaf(c1, x.z, c0) + y.z, 0.f); v.w = fmaxf(fmaf(c1, x.w, c0) + y.w, 0.f);
+        op[i] = v;
+    }
+}
 template <typename F> static double timeit(F f) {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     for (int i = 0; i < 3; ++i) f();
@@ -88,7 +118,9 @@ int main() {
         const double t2 = timeit([&] { hipLaunchKernelGGL(flat, dim3((unsigned)((n4 + 1023) / 1024)), dim3(256), 0, 0, a, b, coef, o, n4, C, L / 4); });
         const int cpr = (L / 4 + 1023) / 1024;
         const double t3 = timeit([&] { hipLaunchKernelGGL(rowchunk, dim3((unsigned)(rows * cpr)), dim3(256), 0, 0, a, b, coef, o, rows, C, L, cpr); });
-        printf("rows %6d x L %6d (%5.0f MB/tensor): rowwise %5.2f TB/s   flat %5.2f TB/s   rowchunk %5.2f TB/s\n", rows, L, n * 4 / 1e6, bytes / t1 / 1e12, bytes / t2 / 1e12, bytes / t3 / 1e12);
+        const double t4 = timeit([&] { hipLaunchKernelGGL(rowwg, dim3(rows), dim3(256), 0, 0, a, b, coef, o, rows, C, L); });
+        const double t5 = timeit([&] { hipLaunchKernelGGL(rowwave, dim3(rows), dim3(64), 0, 0, a, b, coef, o, rows, C, L); });
+        printf("rows %6d x L %6d (%5.0f MB/tensor): rowwise %5.2f TB/s   flat %5.2f   rowchunk %5.2f   rowwg %5.2f   rowwave %5.2f\n", rows, L, n * 4 / 1e6, bytes / t1 / 1e12, bytes / t2 / 1e12, bytes / t3 / 1e12, bytes / t4 / 1e12, bytes / t5 / 1e12);
         (void)hipFree(a); (void)hipFree(b); (void)hipFree(o); (void)hipFree(coef);
     }
     return 0;
