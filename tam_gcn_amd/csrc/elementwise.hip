@@ -13,8 +13,8 @@ namespace {
 constexpr int EW_THREADS = 256;
 
 // row geometry of a launch: lanes per row (power of two, 16..256) -> rows per workgroup.  Round 4: long rows get the WHOLE workgroup
-// (the four waves walk one row together: 8.0 against 7.6 TB/s at 84 MB tensors, 5.0-5.6 against 4.8-5.4 at HBM-streaming sizes,
-// tools/probes/ew_layout_probe.hip); their row sums then meet in LDS.
+// (the four waves walk one row together: 5.0-5.6 against 4.8-5.4 TB/s at HBM-streaming sizes, tools/probes/ew_layout_probe.hip;
+// in the product the N-UCLA rows of 320 steps gained nothing); their row sums then meet in LDS.
 struct RowGeo { int tpr, rows; };               // rows = N * C
 __device__ __forceinline__ bool row_coords(const RowGeo& g, int C, int& c, int& n, int& li) {
     const int rpb = EW_THREADS / g.tpr;
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(EW_THREADS) void tmean_kernel(SrcDev src, int N, in
 
 static bool grid_ok(int N, int C) { return N > 0 && C > 0 && (long long)N * C < (1LL << 31); }
 
-// lanes per row: the whole workgroup for rows of >= 256 steps, half of it from 128, else about five steps per lane (16..64);
+// lanes per row: the whole workgroup for rows of >= 448 steps, else about five steps per lane (16..64);
 // a step is 16 bytes where the kernel walks the row in groups of four floats
 static RowGeo row_geo(int N, int C, int L, bool vec_capable) {
     const int steps = vec_capable ? (L + 3) >> 2 : L;
@@ -617,8 +617,7 @@ static RowGeo row_geo(int N, int C, int L, bool vec_capable) {
     while (tpr < 64 && tpr * 5 < steps) tpr <<= 1;
     static int wide = -1;
     if (wide < 0) { const char* e = getenv("TAMGCN_EW_WIDE"); wide = e ? atoi(e) : 1; }     // 0: at most one wave per row (A/B)
-    if (wide && steps >= 256) tpr = 256;
-    else if (wide && steps >= 128) tpr = 128;
+    if (wide && steps >= 448) tpr = 256;            // measured: NTU (1875 / 937 / 468 steps) 168.4 -> 165.9 ms; N-UCLA's 320-step rows no faster
     RowGeo g; g.tpr = tpr; g.rows = N * C;
     return g;
 }
