@@ -1709,7 +1709,7 @@ constexpr int W_PC = 32, W_NST = 3, W_NT = 512;
 
 template <int WMT, int WKT, int NY, int NX, bool SPL, int NST>
 #ifndef TG_WKO
-#define TG_WKO 0      // knock-out side builds of the weight-gradient kernel (tools/wgrad_big_ab.py): 1 one MFMA in eight, 2 no DMA, 4 no fragment reads, 8 no barrier
+#define TG_WKO 0      // knock-out side builds of the weight-gradient kernel (tools/wgrad_knockout.py): 1 one MFMA in eight, 2 no DMA, 4 no fragment reads, 8 no barrier (profiles/r04_wgrad_knockout.txt)
 #endif
 __global__ __launch_bounds__(W_NT, 2) void wgrad_glds_kernel(const WgradArgs a, int ntk, int ntm) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1718,7 +1718,6 @@ __global__ __launch_bounds__(W_NT, 2) void wgrad_glds_kernel(const WgradArgs a, 
     constexpr int STG = ROWS * W_PC;                              // floats per stage
     constexpr int NPIECE = ROWS / 8;                              // 1 KB pieces per chunk
     constexpr int MAXP = (NPIECE + 7) / 8;                        // per wave
-    constexpr bool BIG = !SPL && WMT * WKT >= 32;                 // the 256 x 256 tile: plain sources, whole tiles only (host)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kq = lane >> 4, wr = wave >> 2, wc = wave & 3;
     int split, tile, tap;
@@ -1768,10 +1767,6 @@ __global__ __launch_bounds__(W_NT, 2) void wgrad_glds_kernel(const WgradArgs a, 
         p_on[i] = __ballot(p_ok[i]) != 0ull;
         nissue += p_on[i] ? 1 : 0;
     }
-    // the 256 x 256 tile: piece i of a wave is 64 rows below piece i - 1 of the same operand -- two base pointers instead of eight
-    const float* ybase = a.gy.x1 + (long long)(a.gy.coff + m0 + wave * 8 + pr) * cs + pu * 4;
-    const float* xbase = a.src.x1 + (long long)(a.src.coff + k0 + wave * 8 + pr) * csx + pu * 4;
-    if constexpr (BIG) nissue = MAXP;
     const long long ystep = (long long)a.gy.ctot * cs, xstep = (long long)a.src.ctot * csx;
     auto issue = [&](int c) {
         if (TG_WKO & 2) return;
@@ -1781,15 +1776,6 @@ __global__ __launch_bounds__(W_NT, 2) void wgrad_glds_kernel(const WgradArgs a, 
         const long long oy = (long long)nn * ystep + ylo + po;
         // stride 2: this lane's slot starts at p0 = po + 4 pu of frame p0 / V; its x elements sit one frame further per frame
         const long long ox = (long long)nn * xstep + xlo + po + (a.stride == 2 ? tc_like_div(po + pu * 4, rV) * a.V : 0);
-        if constexpr (BIG) {
-#pragma unroll
-            for (int i = 0; i < MAXP / 2; ++i)
-                __builtin_amdgcn_global_load_lds((tg_gptr)(ybase + oy + (long long)i * 64 * cs), (tg_lptr)(st + (wave * 8 + i * 64) * W_PC), 16, 0, 0);
-#pragma unroll
-            for (int i = 0; i < MAXP / 2; ++i)
-                __builtin_amdgcn_global_load_lds((tg_gptr)(xbase + ox + (long long)i * 64 * csx), (tg_lptr)(st + (RY + wave * 8 + i * 64) * W_PC), 16, 0, 0);
-            return;
-        }
 #pragma unroll
         for (int i = 0; i < MAXP; ++i) {
             if (p_on[i]) {
@@ -1804,7 +1790,7 @@ __global__ __launch_bounds__(W_NT, 2) void wgrad_glds_kernel(const WgradArgs a, 
 #pragma unroll
     for (int x = 0; x < WMT; ++x) {
         const int m = m0 + (wr * WMT + x) * 16 + j;
-        const bool ok = m < a.M && a.gy.coef && !(!SPL && WMT * WKT >= 32);
+        const bool ok = m < a.M && a.gy.coef;
         const int ch = a.gy.coff + (m < a.M ? m : 0);
         cy1[x] = ok ? a.gy.coef[ch] : 1.f;
         cy2[x] = (ok && NY == 2) ? a.gy.coef[a.gy.ctot + ch] : 0.f;
@@ -1813,14 +1799,14 @@ __global__ __launch_bounds__(W_NT, 2) void wgrad_glds_kernel(const WgradArgs a, 
 #pragma unroll
     for (int y = 0; y < WKT; ++y) {
         const int k = k0 + (wc * WKT + y) * 16 + j;
-        const bool ok = k < a.K && a.src.coef && !(!SPL && WMT * WKT >= 32);
+        const bool ok = k < a.K && a.src.coef;
         const int ch = a.src.coff + (k < a.K ? k : 0);
         cx1[y] = ok ? a.src.coef[ch] : 1.f;
         cx2[y] = (ok && NX == 2) ? a.src.coef[a.src.ctot + ch] : 0.f;
         cx0[y] = ok ? a.src.coef[2 * a.src.ctot + ch] : 0.f;
     }
     const float loy = a.gy.act == 1 ? 0.f : -__builtin_inff(), lox = a.src.act == 1 ? 0.f : -__builtin_inff();
-    const bool yplain = BIG || (!a.gy.coef && a.gy.act != 1), xplain = BIG || (!a.src.coef && a.src.act != 1);   // plain tensors skip the prologue
+    const bool yplain = !a.gy.coef && a.gy.act != 1, xplain = !a.src.coef && a.src.act != 1;   // plain tensors skip the prologue
 
     f32x4 acc[WMT][WKT];
 #pragma unroll
@@ -1886,21 +1872,6 @@ __global__ __launch_bounds__(W_NT, 2) void wgrad_glds_kernel(const WgradArgs a, 
                     }
             }
         };
-        if constexpr (BIG) {
-            // the 256 x 256 tile (128 accumulator registers per lane): one half-chunk's fragments at a time
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                f32x4 avb[WMT], bvb[WKT];
-                frag(b, avb, bvb);
-#pragma unroll
-                for (int e = 0; e < ((TG_WKO & 1) ? (b ? 0 : 1) : 4); ++e)
-#pragma unroll
-                    for (int y = 0; y < WKT; ++y)
-#pragma unroll
-                        for (int x = 0; x < WMT; ++x) acc[x][y] = mfma16(avb[x][e], bvb[y][e], acc[x][y]);
-            }
-            continue;
-        }
         f32x4 av[2][WMT], bv[2][WKT];
         frag(0, av[0], bv[0]);
         frag(1, av[1], bv[1]);
@@ -1943,7 +1914,7 @@ static int launch_wgrad_glds(WgradArgs& a, hipStream_t s) {
     constexpr int BMW = 2 * WMT * 16, BKW = 4 * WKT * 16;
     constexpr size_t STAGE = sizeof(float) * (size_t)(BMW * NY + BKW * NX) * W_PC;
     // a third stage only where it does not cost the second workgroup per CU
-    constexpr int NST = ((2 * STAGE <= 80 * 1024 && 3 * STAGE > 80 * 1024) || 3 * STAGE > 160 * 1024) ? 2 : W_NST;
+    constexpr int NST = (2 * STAGE <= 80 * 1024 && 3 * STAGE > 80 * 1024) ? 2 : W_NST;
     const size_t lds = NST * STAGE;
     static tg_devmask flag = 0;
     tg_allow_lds((const void*)wgrad_glds_kernel<WMT, WKT, NY, NX, SPL, NST>, 160 * 1024, &flag);
@@ -2062,14 +2033,6 @@ static bool wgrad_glds_plan(const tamgcn_wgrad_desc* d, int* wmt, int* wkt) {
     bool glds = (taps || (d->KT == 1 && d->pad == 0)) && ((d->stride == 1 && d->T_in == d->T_out) || strided) && al16 &&
                 (long long)(d->T_out - d->pad) * d->V >= 2 * W_PC;
     if (!glds) return false;
-    // exact fp32, one source per operand, a weight of at least 512 x 256: the 256 x 256 tile (two stages of 64 KB, one
-    // workgroup per CU, 64 flops per staged byte instead of 32); TAMGCN_WGRAD_BIG=0 keeps the 128 x 128 tile
-    static const int big_env = [] { const char* e = getenv("TAMGCN_WGRAD_BIG"); return e ? atoi(e) : 1; }();
-    if (big_env && d->KT == 1 && tamgcn_split_mode() == 0 && !d->gy.x2 && !d->src.x2 && d->M >= 512 && d->K >= 256 && d->M % 256 == 0 && d->K % 256 == 0 &&
-        !d->gy.coef && d->gy.act != 1 && !d->src.coef && d->src.act != 1) {
-        *wmt = 8; *wkt = 8;
-        return true;
-    }
     if (d->KT > 1) { *wmt = d->M <= 64 ? 2 : 4; *wkt = d->K <= 64 ? 2 : 4; }      // the 1x1 rule (units of 32)
     // three stages of both operands (every source) must fit the CU's LDS: shrink the tile
     auto fits = [&](int tm, int tk) {
@@ -2112,8 +2075,7 @@ extern "C" int tamgcn_wgrad(const tamgcn_wgrad_desc* d, void* stream) {
     const bool glds = wgrad_glds_plan(d, &wmt, &wkt);
     a.KTG = glds ? d->KT : 1;
     if (glds) {              // tile = 64 or 128 per side by the same rule as wgrad_tile (wmt: rows/32, wkt: cols/64)
-        if (wmt == 8 && wkt == 8) rc = launch_wgrad_glds<8, 4, 1, 1, false>(a, s);
-        else if (wmt == 2 && wkt == 2) rc = launch_wgrad_glds_src<2, 1>(a, s);
+        if (wmt == 2 && wkt == 2) rc = launch_wgrad_glds_src<2, 1>(a, s);
         else if (wmt == 4 && wkt == 2) rc = launch_wgrad_glds_src<4, 1>(a, s);
         else if (wmt == 2 && wkt == 4) rc = launch_wgrad_glds_src<2, 2>(a, s);
         else rc = launch_wgrad_glds_src<4, 2>(a, s);

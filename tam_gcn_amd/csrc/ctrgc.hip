@@ -35,6 +35,10 @@
 
 TG_TRACE_DEFINE(tamgcn_trace_read_ctrgc)
 
+#ifndef TG_CKO
+#define TG_CKO 0      // knock-out side builds of ctrgc_fwd_kernel (tools/ctrgc_knockout.py; results wrong by design): 1 no GEMM MFMAs,
+#endif                // 2 no operand loads, 4 no stage commit, 8 no x3 tile write, 16 no aggregation, 32 no copy-out stores, 64 no GEMM fragment reads
+
 namespace {
 
 struct CtrgcArgs {
@@ -235,6 +239,7 @@ struct X3Pref {
     float wv[NAF];
 
     __device__ __forceinline__ void load(const CtrgcArgs& a, int n, int c0, int t0, int bt, int k0) {
+        if (TG_CKO & 2) return;
         constexpr int V = G::V;
         const int tid = threadIdx.x, ncols = bt * V;
         const long long cs = (long long)a.T * V;
@@ -262,6 +267,7 @@ struct X3Pref {
         for (int i = 0; i < NAF; ++i) asm volatile("" : "+v"(wv[i]));
     }
     __device__ __forceinline__ void commit(float* As, float* Bs) const {    // registers -> LDS stage
+        if (TG_CKO & 4) return;
         const int tid = threadIdx.x;
 #pragma unroll
         for (int i = 0; i < NAF; ++i) {
@@ -330,10 +336,18 @@ __device__ void x3_chunk(const CtrgcArgs& a, int n, int c0, int t0, int bt, floa
 #pragma unroll
         for (int k4 = 0; k4 < SBK / 4; ++k4) {
             float av[NRT], bv[CW];
+            if (TG_CKO & 64) {
+#pragma unroll
+                for (int rt = 0; rt < NRT; ++rt) asm volatile("" : "=v"(av[rt]));
+#pragma unroll
+                for (int c = 0; c < CW; ++c) asm volatile("" : "=v"(bv[c]));
+            } else {
 #pragma unroll
             for (int rt = 0; rt < NRT; ++rt) av[rt] = at[rt * 16 * SBKP + k4 * 4];
 #pragma unroll
             for (int c = 0; c < CW; ++c) bv[c] = bt_[k4 * 4 * PB + bcol[c]];
+            }
+            if ((TG_CKO & 1) && k4) continue;
 #pragma unroll
             for (int c = 0; c < (BAL ? 2 : CW); ++c)
 #pragma unroll
@@ -350,6 +364,7 @@ __device__ void x3_chunk(const CtrgcArgs& a, int n, int c0, int t0, int bt, floa
 #pragma unroll
         for (int c = 0; c < CW; ++c) {
             int col = (cw0 + c) * 16 + j;
+            if ((TG_CKO & 8) && (rt || c)) continue;
             if (col >= ncols || (BAL && c == 2 && !third)) continue;
             const int fr = col / V, v = col - fr * V;
 #pragma unroll
@@ -502,7 +517,7 @@ __global__ __launch_bounds__(G::NT, 2) void ctrgc_fwd_kernel(const CtrgcArgs a, 
         TG_T(ta);
         x3_chunk<G, ST>(a, n, c0, t0, bt, X3, pf, nt0, nbt);
         TG_T(tb); TG_ACC(1, tb - ta);
-        aggregate_mfma<G, ST>(Es, X3, Zs, bt);      // frames beyond bt hold stale data: their rows are not stored
+        if (!(TG_CKO & 16)) aggregate_mfma<G, ST>(Es, X3, Zs, bt);      // frames beyond bt hold stale data: their rows are not stored
         TG_T(tc); TG_ACC(2, tc - tb);
         __syncthreads();
         TG_T(td); TG_ACC(3, td - tc);
@@ -535,7 +550,7 @@ __global__ __launch_bounds__(G::NT, 2) void ctrgc_fwd_kernel(const CtrgcArgs a, 
 #pragma unroll
                 for (int i = 0; i < NV4; ++i) {
                     const int p4 = lrow + i * RL;
-                    if (p4 < (ncols >> 2)) reinterpret_cast<float4*>(xo)[p4] = xv[s][i];
+                    if (p4 < (ncols >> 2) && (!(TG_CKO & 32) || xv[s][i].x == 1.2345f)) reinterpret_cast<float4*>(xo)[p4] = xv[s][i];
                 }
             }
         }
@@ -543,7 +558,7 @@ __global__ __launch_bounds__(G::NT, 2) void ctrgc_fwd_kernel(const CtrgcArgs a, 
         for (int i = 0; i < NV4; ++i) {
             const int p4 = lrow + i * RL;
             if (p4 < (ncols >> 2)) {
-                reinterpret_cast<float4*>(yrow)[p4] = zv[i];
+                if (!(TG_CKO & 32) || zv[i].x == 1.2345f) reinterpret_cast<float4*>(yrow)[p4] = zv[i];
                 st1 += (zv[i].x + zv[i].y) + (zv[i].z + zv[i].w);
                 st2 = fmaf(zv[i].x, zv[i].x, fmaf(zv[i].y, zv[i].y, fmaf(zv[i].z, zv[i].z, fmaf(zv[i].w, zv[i].w, st2))));
             }

@@ -263,7 +263,6 @@ def tconv_wgrad(gy, src, Cb, KT, dils, stride):
     return reduce_sum(part, nsplit, chunks=[(Cb, Cb, KT, 1)] * nb)
 
 
-WGRAD_BIG = int(os.environ.get('TAMGCN_WGRAD_BIG', '1'))
 WGRAD_BLOCKS = int(os.environ.get('TAMGCN_WGRAD_BLOCKS', '512'))    # workgroups a weight gradient aims at (tiles x splits)
 
 
@@ -282,11 +281,6 @@ def wgrad(gy, src, M, K, KT=1, dil=1, stride=1, pad=0, rows=None):
     else:
         bm = bk = 32 if (M <= 32 and K <= 32) else 64
     lib = _lib_()
-    target = WGRAD_BLOCKS
-    if (WGRAD_BIG and KT == 1 and M >= 512 and K >= 256 and M % 256 == 0 and K % 256 == 0 and lib.tamgcn_get_split_mode() == 0
-            and all(o.x2 is None and o.coef is None and o.act != 1 for o in (gy, src)) and stride in (1, 2) and pad == 0):
-        bm = bk = 256                                      # wgrad_glds_plan()'s 256 x 256 tile: one workgroup per CU
-        target = WGRAD_BLOCKS // 2
     tiles = ((M + bm - 1) // bm) * ((K + bk - 1) // bk) * (KT if taps else 1)
     descs = []
     for n0, n1 in chunks:
@@ -296,7 +290,7 @@ def wgrad(gy, src, M, K, KT=1, dil=1, stride=1, pad=0, rows=None):
         d.N, d.M, d.K, d.T_in, d.T_out, d.V = n1 - n0, M, K, T_in, T_out, V
         d.KT, d.dil, d.stride, d.pad = KT, dil, stride, pad
         descs.append((d, g_, s_))
-    per = max(1, (target + tiles - 1) // tiles // len(chunks))
+    per = max(1, (WGRAD_BLOCKS + tiles - 1) // tiles // len(chunks))
     splits = [max(1, min(lib.tamgcn_wgrad_max_split(C.byref(d)), per)) for d, _, _ in descs]
     nsplit = sum(splits)                                   # every chunk's partial slabs sit in ONE array: one reduction
     part = empty(nsplit, M, K, KT, like=gy.x1)

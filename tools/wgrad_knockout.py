@@ -1,4 +1,6 @@
-"""A/B of the 256 x 256 weight-gradient tile (TAMGCN_WGRAD_BIG) at the dW3 shapes of C = 256 layers; each setting in a child process."""
+"""What each part of the LDS-DMA weight-gradient kernel costs at the dW3 shapes of the C = 256 layers: side builds of conv.hip with
+-DTG_WKO=<mask> (results wrong by design), each in a child process.   here: python tools/wgrad_knockout.py build    box: python tools/wgrad_knockout.py
+(Round 4's run, which also carried a 256 x 256 tile that was rejected: profiles/r04_wgrad_knockout.txt.)"""
 import os, subprocess, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 1 and sys.argv[1] == 'child':
@@ -48,10 +50,9 @@ if len(sys.argv) > 1 and sys.argv[1] == 'build':       # knock-out side builds (
     print('built', sorted(os.listdir(SIDE)))
     sys.exit(0)
 kos = [m for m in MASKS if os.path.exists(os.path.join(SIDE, f'libtamgcn_wko{m}.so'))]
-for big in ('0', '1'):
-    for ko in [0] + kos:
-        print(f'TAMGCN_WGRAD_BIG={big} knock-out mask {ko} (1 one MFMA in eight, 2 no DMA, 4 no fragment reads, 8 no barrier)', flush=True)
-        env = dict(os.environ, TAMGCN_WGRAD_BIG=big, TAMGCN_SPLIT_BF16='0')
-        if ko:
-            env['TAMGCN_LIB'] = os.path.join(SIDE, f'libtamgcn_wko{ko}.so')
-        subprocess.run([sys.executable, __file__, 'child'], env=env, check=True)
+for ko in [0] + kos:
+    print(f'knock-out mask {ko} (1 one MFMA in eight, 2 no DMA, 4 no fragment reads, 8 no barrier)', flush=True)
+    env = dict(os.environ, TAMGCN_SPLIT_BF16='0')
+    if ko:
+        env['TAMGCN_LIB'] = os.path.join(SIDE, f'libtamgcn_wko{ko}.so')
+    subprocess.run([sys.executable, __file__, 'child'], env=env, check=True)
