@@ -79,6 +79,7 @@ struct Plan {
     static constexpr int REGION = ((STAGE > X3T ? STAGE : X3T) + 3) & ~3;      // the stage aliases the x3 tile
     static constexpr int ETILE = (NR * G::VV + 255) & ~255;                    // E tiles, whole 1 KB DMA pieces
     static constexpr size_t LDS = sizeof(float) * ((size_t)ETILE + REGION + (size_t)G::CT * G::NCOLS);
+    static constexpr size_t LDS_NOE = sizeof(float) * ((size_t)REGION + (size_t)G::CT * G::NCOLS);   // E read from L2 per channel (forward, ER = false)
 };
 
 // blockIdx -> (n, channel tile); blocks that share n are b, b+8, ... => same XCD / L2
@@ -99,6 +100,17 @@ __device__ __forceinline__ bool block_coords(const CtrgcArgs& a, int& n, int& c0
 // is linear, so the layout change sits in the per-lane SOURCE address; no registers, no LDS store instructions, and the
 // transfer overlaps whatever the workgroup requests next (the first operand chunk).  It is complete at the first
 // __syncthreads() after the call (hipcc drains outstanding LDS-DMA there) -- the caller's first barrier.
+// wave-uniform base + 32-bit byte offset: one SGPR pair and one VGPR per address (the 64-bit per-lane pointers the compiler
+// otherwise builds -- and hoists out of the frame loop -- cost two registers each)
+template <class T>
+__device__ __forceinline__ const T* cg_at(const void* base, unsigned byte_off) {
+    return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <class T>
+__device__ __forceinline__ T* cg_at_w(void* base, unsigned byte_off) {
+    return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off);
+}
+
 typedef __attribute__((address_space(1))) const void* cg_gptr;
 typedef __attribute__((address_space(3))) void* cg_lptr;
 
@@ -238,26 +250,27 @@ struct X3Pref {
     float4 rv[NPF];
     float wv[NAF];
 
-    __device__ __forceinline__ void load(const CtrgcArgs& a, int n, int c0, int t0, int bt, int k0) {
+    __device__ __forceinline__ void load(const CtrgcArgs& a, int n, int c0, int t0, int bt, int k0, int tid) {
         if (TG_CKO & 2) return;
         constexpr int V = G::V;
-        const int tid = threadIdx.x, ncols = bt * V;
-        const long long cs = (long long)a.T * V;
-        const long long xb = ((long long)n * a.x_ctot + a.x_coff) * cs + (long long)t0 * V;
+        const int ncols = bt * V;
+        const int cs = a.T * V;                                     // host: 4 * SBK * T * V < 2^32
+        const float* xk = a.x + ((long long)n * a.x_ctot + a.x_coff + k0) * cs + (long long)t0 * V;    // wave-uniform
+        const float* wk = a.w3 + (long long)c0 * a.Cin + k0;                                            // wave-uniform
 #pragma unroll
         for (int i = 0; i < NAF; ++i) {
             const int e = tid + i * NT;
             const int kk = e % SBK, row = e / SBK;
-            const int sidx = row / CT, c = row - sidx * CT, k = k0 + kk;
-            wv[i] = (row < P::NR && k < a.Cin) ? a.w3[((long long)sidx * a.Cout + c0 + c) * a.Cin + k] : 0.f;
+            const int sidx = row / CT, c = row - sidx * CT;
+            const bool ok = row < P::NR && k0 + kk < a.Cin;
+            wv[i] = ok ? *cg_at<float>(wk, 4u * (unsigned)((sidx * a.Cout + c) * a.Cin + kk)) : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
             const int e = tid + i * NT;
             const int kk = e / ROWV, pos = (e - kk * ROWV) * 4;
-            const int k = k0 + kk;
-            const bool ok = kk < SBK && k < a.Cin && pos < ncols;
-            rv[i] = ok ? *reinterpret_cast<const float4*>(a.x + xb + (long long)k * cs + pos) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = kk < SBK && k0 + kk < a.Cin && pos < ncols;
+            rv[i] = ok ? *cg_at<float4>(xk, 4u * (unsigned)(kk * cs + pos)) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     __device__ __forceinline__ void pin() {
@@ -266,9 +279,8 @@ struct X3Pref {
 #pragma unroll
         for (int i = 0; i < NAF; ++i) asm volatile("" : "+v"(wv[i]));
     }
-    __device__ __forceinline__ void commit(float* As, float* Bs) const {    // registers -> LDS stage
+    __device__ __forceinline__ void commit(float* As, float* Bs, int tid) const {    // registers -> LDS stage
         if (TG_CKO & 4) return;
-        const int tid = threadIdx.x;
 #pragma unroll
         for (int i = 0; i < NAF; ++i) {
             const int e = tid + i * NT;
@@ -290,13 +302,13 @@ struct X3Pref {
 // frame chunk (loaded by the caller, or by the previous call); when a next frame chunk exists its first K chunk is
 // requested right after the K loop, so that it travels under the tile write, the aggregation and the copy-out.
 // ---------------------------------------------------------------------------
-template <class G, int ST>
-__device__ void x3_chunk(const CtrgcArgs& a, int n, int c0, int t0, int bt, float* X3, X3Pref<G, ST>& pf, int next_t0, int next_bt) {
+template <class G, int ST, class Pre>
+__device__ __forceinline__ void x3_chunk(const CtrgcArgs& a, int n, int c0, int t0, int bt, float* X3, X3Pref<G, ST>& pf, int next_t0, int next_bt, int tid, Pre&& pre) {
     // the tile leaves as X3[(c*BT + frame)*KP + s*V + v], KP = S*V: a (channel, frame) row holds the aggregation's k axis
     using P = Plan<G, ST>;
     constexpr int V = G::V, CW = G::CW, SBK = G::SBK, SBKP = G::SBKP, CT = G::CT;
     constexpr int NR = P::NR, NRT = P::NRT, PB = G::PITCHB;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kq = lane >> 4;
     const int ncols = bt * V;
     // Column tiles per wave.  Waves w and w + 4 share a SIMD (its MFMA pipe): with 20 tiles on 8 waves, "3 per wave in
@@ -327,10 +339,10 @@ __device__ void x3_chunk(const CtrgcArgs& a, int n, int c0, int t0, int bt, floa
         }
     for (int k0 = 0; k0 < a.Cin; k0 += SBK) {
         __syncthreads();                               // previous users of the region are done
-        pf.commit(As, Bs);
+        pf.commit(As, Bs, tid);
         __syncthreads();
-        if (k0 + SBK < a.Cin) pf.load(a, n, c0, t0, bt, k0 + SBK);      // in flight under the MFMAs
-        else if (next_bt > 0) pf.load(a, n, c0, next_t0, next_bt, 0);   // the next frame chunk's first K chunk
+        if (k0 + SBK < a.Cin) pf.load(a, n, c0, t0, bt, k0 + SBK, tid);      // in flight under the MFMAs
+        else if (next_bt > 0) pf.load(a, n, c0, next_t0, next_bt, 0, tid);   // the next frame chunk's first K chunk
         const float* at = As + j * SBKP + kq;
         const float* bt_ = Bs + kq * PB;
 #pragma unroll
@@ -358,6 +370,7 @@ __device__ void x3_chunk(const CtrgcArgs& a, int n, int c0, int t0, int bt, floa
             }
         }
     }
+    pre();                                             // the caller's requests that should travel under the tile write
     __syncthreads();                                   // stage dead; X3 may be overwritten
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt) {
@@ -432,6 +445,76 @@ __device__ __forceinline__ void aggregate_mfma(const float* Ek, const float* X3,
     }
 }
 
+// The same product with the B fragments (rows of E) taken from global memory instead of an LDS-resident tile: lane (j, kq)'s vector m
+// of row u is E[n][s][c][u][v0 .. v0+3] with 16 m + 4 kq = s V + v0 (V % 4 == 0: a vector never leaves its subset) -- the layout
+// tamgcn_ctrgc_build_e writes, read as it lies.  A workgroup re-reads its 77 KB per frame chunk from L2; without the tile two
+// 16-channel workgroups share a CU.  ld() requests one channel's fragments; the caller requests the first channel's before the
+// x3 tile write so that they travel under it.
+template <class G, int ST>
+struct EFrag {
+    static constexpr int V = G::V, KP = ST * V, NM = (KP + 15) / 16, NUT = (V + 15) / 16;
+    f32x4 bv[NUT][NM];
+    __device__ __forceinline__ void ld(const float* __restrict__ En, int Cout, int ch, int tid) {   // En = E + n*S*Cout*VV, ch = absolute channel (wave-uniform)
+        const int lane = tid & 63, j = lane & 15, kq = lane >> 4;
+        const float* Ec = En + ch * G::VV;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const int k = 16 * m + 4 * kq;
+            const bool in = k < KP;
+            const int kk = in ? k : 0, sidx = kk / V, v0 = kk - sidx * V;
+#pragma unroll
+            for (int ut = 0; ut < NUT; ++ut) {
+                const int u = ut * 16 + j < V ? ut * 16 + j : V - 1;
+                const f32x4 v = *cg_at<f32x4>(Ec, 4u * (unsigned)(sidx * Cout * G::VV + u * V + v0));
+                bv[ut][m] = in ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
+};
+
+template <class G, int ST, bool DB = false>      // DB: the next channel's fragments in a second register set
+__device__ __forceinline__ void aggregate_mfma_g(const float* __restrict__ En, int Cout, int c0, EFrag<G, ST>& e0, const float* X3, float* Zs, int bt, int tid) {
+    constexpr int V = G::V, CT = G::CT, KP = ST * V, NM = (KP + 15) / 16, NUT = (V + 15) / 16;
+    static_assert(G::BT == 16, "one 16-frame MFMA row tile per chunk");
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int ci = 0; ci < CT / G::NW; ++ci) {
+        const int c = wave + ci * G::NW;
+        EFrag<G, ST> en;
+        if (DB && ci + 1 < CT / G::NW) en.ld(En, Cout, c0 + c + G::NW, tid);
+        f32x4 av[NM];
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const bool in = 16 * m + 4 * kq < KP;
+            av[m] = *reinterpret_cast<const f32x4*>(X3 + (c * G::BT + j) * KP + (in ? 16 * m + 4 * kq : 0));
+            if (!in) av[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        f32x4 acc[NUT];
+#pragma unroll
+        for (int ut = 0; ut < NUT; ++ut) acc[ut] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < NM; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int ut = 0; ut < NUT; ++ut) acc[ut] = mfma16(av[m][r], e0.bv[ut][m][r], acc[ut]);
+#pragma unroll
+        for (int ut = 0; ut < NUT; ++ut) {
+            const int u = ut * 16 + j;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int fr = kq * 4 + r;
+                if (u < V && fr < bt) Zs[c * G::NCOLS + fr * V + u] = acc[ut][r];
+            }
+        }
+        if (ci + 1 < CT / G::NW) {
+            if (DB) e0 = en;
+            else e0.ld(En, Cout, c0 + c + G::NW, tid);                        // no registers for a second set
+        }
+    }
+}
+
 // dy chunk [CT][ncols] of frames [t0, t0+bt): loads (with the BatchNorm-backward prologue operands)
 // go to registers first, commit() applies the prologue and stores to LDS.  NDY vectors per thread.
 template <class G>
@@ -489,24 +572,24 @@ struct DyTile {
 // ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
-template <class G, int ST>
-__global__ __launch_bounds__(G::NT, 2) void ctrgc_fwd_kernel(const CtrgcArgs a, float* y, float* stats_part, float* x3_out) {
+template <class G, int ST, bool ER = true>       // ER: the E tile resident in LDS (one 16-channel workgroup per CU) or read from L2 per channel (two)
+__global__ __launch_bounds__(G::NT, ER ? 2 : 4) void ctrgc_fwd_kernel(const CtrgcArgs a, float* y, float* stats_part, float* x3_out) {
     using P = Plan<G, ST>;
     constexpr int V = G::V, CT = G::CT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int n, c0;
     if (!block_coords<G>(a, n, c0)) return;
     float* Es = smem;                                  // [CT][V][S*V]: row (c, u) = E_s[c][u][v] over (s, v)
-    float* X3 = Es + P::ETILE;                         // REGION floats: GEMM stage, then the x3 tile [CT][BT][S*V]
+    float* X3 = ER ? Es + P::ETILE : smem;             // REGION floats: GEMM stage, then the x3 tile [CT][BT][S*V]
     float* Zs = X3 + P::REGION;                        // [CT][NCOLS]
-    const int tid = threadIdx.x;
-    const int c = tid / (G::NTQ * 4);
-    const int lrow = tid % (G::NTQ * 4);               // lane index inside the channel row (copy-out)
+    const int tid0 = threadIdx.x;
+    const float* En = a.E + (long long)n * ST * a.Cout * G::VV;
+    static_assert(ER || CT % G::NW == 0, "whole channels per wave");
 
     TG_T(tt0);
     X3Pref<G, ST> pf;
-    pf.load(a, n, c0, 0, min(G::BT, a.T), 0);          // first operands of the first chunk: in flight under the E load
-    load_E_k<G, ST>(a.E, a.Cout, n, c0, Es);
+    pf.load(a, n, c0, 0, min(G::BT, a.T), 0, tid0);          // first operands of the first chunk: in flight under the E load
+    if constexpr (ER) load_E_k<G, ST>(a.E, a.Cout, n, c0, Es);
     TG_T(tt1); TG_ACC(0, tt1 - tt0);
 
     float st1 = 0.f, st2 = 0.f;
@@ -514,10 +597,18 @@ __global__ __launch_bounds__(G::NT, 2) void ctrgc_fwd_kernel(const CtrgcArgs a, 
         const int bt = min(G::BT, a.T - t0);
         const int ncols = bt * V;
         const int nt0 = t0 + G::BT, nbt = nt0 < a.T ? min(G::BT, a.T - nt0) : 0;
+        // 128 registers per wave (ER = false): everything derived from the thread index is recomputed per frame chunk instead of
+        // being hoisted out of this loop and spilled (a scratch reload is a vmcnt wait behind every prefetch in flight)
+        int tid = tid0;
+        if constexpr (!ER) asm volatile("" : "+v"(tid));
+        const int c = tid / (G::NTQ * 4);
+        const int lrow = tid % (G::NTQ * 4);           // lane index inside the channel row (copy-out)
         TG_T(ta);
-        x3_chunk<G, ST>(a, n, c0, t0, bt, X3, pf, nt0, nbt);
+        EFrag<G, ST> ef;
+        x3_chunk<G, ST>(a, n, c0, t0, bt, X3, pf, nt0, nbt, tid, [&] { if constexpr (!ER) ef.ld(En, a.Cout, c0 + __builtin_amdgcn_readfirstlane(tid >> 6), tid); });
         TG_T(tb); TG_ACC(1, tb - ta);
-        if (!(TG_CKO & 16)) aggregate_mfma<G, ST>(Es, X3, Zs, bt);      // frames beyond bt hold stale data: their rows are not stored
+        if constexpr (!ER) aggregate_mfma_g<G, ST>(En, a.Cout, c0, ef, X3, Zs, bt, tid);
+        else if (!(TG_CKO & 16)) aggregate_mfma<G, ST>(Es, X3, Zs, bt);      // frames beyond bt hold stale data: their rows are not stored
         TG_T(tc); TG_ACC(2, tc - tb);
         __syncthreads();
         TG_T(td); TG_ACC(3, td - tc);
@@ -525,7 +616,8 @@ __global__ __launch_bounds__(G::NT, 2) void ctrgc_fwd_kernel(const CtrgcArgs a, 
         // read only; vmcnt retires in order, so interleaving reads and stores serialises them)
         constexpr int RL = G::NTQ * 4;                              // lanes per channel row
         constexpr int NV4 = (G::NCOLS / 4 + RL - 1) / RL;           // float4 per lane and row
-        float* yrow = y + (((long long)n * a.Cout + c0 + c) * a.T + t0) * V;
+        float* ybase = y + (((long long)n * a.Cout + c0) * a.T + t0) * V;          // wave-uniform; rows by 32-bit byte offsets
+        const unsigned rowb = 4u * (unsigned)(c * a.T * V);
         float4 zv[NV4];
 #pragma unroll
         for (int i = 0; i < NV4; ++i) {
@@ -533,6 +625,27 @@ __global__ __launch_bounds__(G::NT, 2) void ctrgc_fwd_kernel(const CtrgcArgs a, 
             zv[i] = p4 < (ncols >> 2) ? reinterpret_cast<const float4*>(Zs + c * G::NCOLS)[p4] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         if (nbt > 0) pf.pin();    // the next chunk's operands have landed: no load is left in front of the stores below
+        if constexpr (!ER) {      // 128 registers per wave: one subset's vectors at a time
+            if (x3_out) {
+#pragma unroll
+                for (int s = 0; s < ST; ++s) {
+                    float4 xs[NV4];
+#pragma unroll
+                    for (int i = 0; i < NV4; ++i) {
+                        const int p4 = lrow + i * RL;
+                        const int fr = p4 / (V / 4), q = p4 - fr * (V / 4);
+                        xs[i] = p4 < (ncols >> 2) ? *reinterpret_cast<const float4*>(X3 + (c * G::BT + fr) * (ST * V) + s * V + 4 * q)
+                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                    float* xo = x3_out + (((long long)n * ST * a.Cout + s * a.Cout + c0) * a.T + t0) * V;
+#pragma unroll
+                    for (int i = 0; i < NV4; ++i) {
+                        const int p4 = lrow + i * RL;
+                        if (p4 < (ncols >> 2)) *cg_at_w<float4>(xo, rowb + 16u * (unsigned)p4) = xs[i];
+                    }
+                }
+            }
+        } else
         if (x3_out) {             // keep x3 for the backward (saves recomputing the GEMM there)
             float4 xv[ST][NV4];
 #pragma unroll
@@ -546,11 +659,11 @@ __global__ __launch_bounds__(G::NT, 2) void ctrgc_fwd_kernel(const CtrgcArgs a, 
                 }
 #pragma unroll
             for (int s = 0; s < ST; ++s) {
-                float* xo = x3_out + (((long long)n * ST * a.Cout + s * a.Cout + c0 + c) * a.T + t0) * V;
+                float* xo = x3_out + (((long long)n * ST * a.Cout + s * a.Cout + c0) * a.T + t0) * V;
 #pragma unroll
                 for (int i = 0; i < NV4; ++i) {
                     const int p4 = lrow + i * RL;
-                    if (p4 < (ncols >> 2) && (!(TG_CKO & 32) || xv[s][i].x == 1.2345f)) reinterpret_cast<float4*>(xo)[p4] = xv[s][i];
+                    if (p4 < (ncols >> 2) && (!(TG_CKO & 32) || xv[s][i].x == 1.2345f)) *cg_at_w<float4>(xo, rowb + 16u * (unsigned)p4) = xv[s][i];
                 }
             }
         }
@@ -558,7 +671,7 @@ __global__ __launch_bounds__(G::NT, 2) void ctrgc_fwd_kernel(const CtrgcArgs a, 
         for (int i = 0; i < NV4; ++i) {
             const int p4 = lrow + i * RL;
             if (p4 < (ncols >> 2)) {
-                if (!(TG_CKO & 32) || zv[i].x == 1.2345f) reinterpret_cast<float4*>(yrow)[p4] = zv[i];
+                if (!(TG_CKO & 32) || zv[i].x == 1.2345f) *cg_at_w<float4>(ybase, rowb + 16u * (unsigned)p4) = zv[i];
                 st1 += (zv[i].x + zv[i].y) + (zv[i].z + zv[i].w);
                 st2 = fmaf(zv[i].x, zv[i].x, fmaf(zv[i].y, zv[i].y, fmaf(zv[i].z, zv[i].z, fmaf(zv[i].w, zv[i].w, st2))));
             }
@@ -571,7 +684,222 @@ __global__ __launch_bounds__(G::NT, 2) void ctrgc_fwd_kernel(const CtrgcArgs a, 
         // reduce over the NTQ*4 threads of the channel row (consecutive lanes of one wave)
 #pragma unroll
         for (int o = 1; o < G::NTQ * 4; o <<= 1) { st1 += __shfl_xor(st1, o); st2 += __shfl_xor(st2, o); }
+        const int c = tid0 / (G::NTQ * 4), lrow = tid0 % (G::NTQ * 4);
         if (lrow == 0) {
+            stats_part[((long long)0 * a.Cout + c0 + c) * a.N + n] = st1;
+            stats_part[((long long)1 * a.Cout + c0 + c) * a.N + n] = st2;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// forward, second form (round 4): TWO 16-channel workgroups per CU.  profiles/r04_ctrgc_fwd_knockout.txt: the x3 GEMM of the form
+// above already runs at the rate the matrix cores sustain; the aggregation, the tile write, the copy-out and the start-up are
+// serial to it, and with E resident (77 KB) nothing else fits the CU.  Here
+//   * E is NOT resident: the aggregation's B fragments are 16-byte rows of E as tamgcn_ctrgc_build_e wrote them, loaded into
+//     registers one channel ahead (EFrag); the workgroup's 77 KB stay in L2 between frame chunks.  LDS = x3 tile + z tile = 80 KB;
+//   * the x3 GEMM's operands travel by LDS-DMA into two 25 KB stages inside the x3 tile's region (16 input channels each):
+//     no staging registers, no commit pass, one barrier per K chunk -- the register-staged form spent 28 % of the launch on the
+//     loads and their commit once two workgroups shared the CU;
+//   * 128 registers per wave: everything derived from the thread index is recomputed per frame chunk (an opaque copy of it) --
+//     hoisted out of the loop the compiler spilled 143 registers, and a scratch reload is a vmcnt wait behind every request in flight;
+//   * the first stage of the NEXT frame chunk is requested after the copy-out's LDS reads and BEFORE its global stores (vmcnt
+//     retires in order): the next chunk's first wait allows exactly those stores to be still in flight.
+// Applies to S = 3, Cout % 16 == 0, Cin % 16 == 0, 16-byte aligned x and w3; everything else stays on ctrgc_fwd_kernel.
+// ---------------------------------------------------------------------------
+#define CG_VMCNT_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+__device__ __forceinline__ void cg_wait_vmcnt(int n) {     // n is wave-uniform
+    switch (n) {
+        CG_VMCNT_CASE(0) CG_VMCNT_CASE(1) CG_VMCNT_CASE(2) CG_VMCNT_CASE(3) CG_VMCNT_CASE(4) CG_VMCNT_CASE(5) CG_VMCNT_CASE(6)
+        CG_VMCNT_CASE(7) CG_VMCNT_CASE(8) CG_VMCNT_CASE(9) CG_VMCNT_CASE(10) CG_VMCNT_CASE(11) CG_VMCNT_CASE(12)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+template <class G, int ST>
+struct Fwd2 {
+    using P = Plan<G, ST>;
+    static constexpr int SBK = 16, PB = G::PITCHB, AP = 20;           // input channels per stage; x row pitch, weight row pitch (floats)
+    static constexpr int RS = PB / 4;                                 // 16-byte slots per x row (NCOLS / 4 of them used)
+    static constexpr int XSL = SBK * RS;                              // slots of the x image
+    static constexpr int ASL = P::NR * (AP / 4);                      // slots of the weight image (AP / 4 per row, SBK / 4 used)
+    static constexpr int NPIECE = (XSL + ASL + 63) / 64, NPW = (NPIECE + G::NW - 1) / G::NW;
+    static constexpr int STG = NPIECE * 256;                          // floats per stage: whole 1 KB pieces
+    static_assert(P::NR == P::NRT * 16, "full weight row tiles");
+    static_assert(2 * STG <= P::REGION, "both stages inside the x3 tile's region");
+    static_assert(XSL % 64 == 0, "a piece holds x slots or weight slots, not both");
+};
+
+template <class G, int ST>
+__global__ __launch_bounds__(G::NT, 4) void ctrgc_fwd2_kernel(const CtrgcArgs a, float* y, float* stats_part, float* x3_out) {
+    using P = Plan<G, ST>;
+    using F = Fwd2<G, ST>;
+    constexpr int V = G::V, CT = G::CT, NRT = P::NRT, CW = G::CW, PB = F::PB, AP = F::AP, SBK = F::SBK;
+    static_assert(G::NW == 8 && G::NCT == 20 && CW == 3 && CT % G::NW == 0, "the 16-channel geometry");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int n, c0;
+    if (!block_coords<G>(a, n, c0)) return;
+    float* X3 = smem;                                  // REGION floats: two GEMM stages, then the x3 tile [CT][BT][S*V]
+    float* Zs = X3 + P::REGION;                        // [CT][NCOLS]
+    const int tid0 = threadIdx.x;
+    const float* En = a.E + (long long)n * ST * a.Cout * G::VV;
+    const int cs = a.T * V;                            // host: 64 * T * V < 2^32
+    const int nk = a.Cin / SBK;                        // host: Cin % 16 == 0
+    const float* xn = a.x + ((long long)n * a.x_ctot + a.x_coff) * cs;    // wave-uniform
+    const float* wk0 = a.w3 + (long long)c0 * a.Cin;                      // wave-uniform
+    constexpr int RL = G::NTQ * 4;                                        // lanes per channel row (copy-out)
+    constexpr int NV4 = (G::NCOLS / 4 + RL - 1) / RL;                     // float4 per lane and row
+    const int nst = NV4 * (x3_out ? ST + 1 : 1);                          // store instructions of one copy-out
+
+    // one K chunk (16 input channels from k0) of the frames from t0 into stage `stage`: per lane a 16-byte slot of each of the
+    // wave's pieces -- the image is linear in LDS, the layout sits in the source address
+    auto issue = [&](int stage, int t0, int ncols, int k0, int tid) {
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        float* st = X3 + stage * F::STG;
+        const float* xk = xn + (long long)k0 * cs + (long long)t0 * V;
+        const float* wk = wk0 + k0;
+#pragma unroll
+        for (int i = 0; i < F::NPW; ++i) {
+            const int p = wave + i * G::NW;                                // wave-uniform
+            if (p < F::NPIECE) {
+                const int L = p * 64 + lane;
+                if (p * 64 < F::XSL) {
+                    const int row = L / F::RS, c4 = L - row * F::RS;
+                    if (c4 * 4 < ncols)
+                        __builtin_amdgcn_global_load_lds((cg_gptr)cg_at<float>(xk, 4u * (unsigned)(row * cs + c4 * 4)), (cg_lptr)(st + p * 256), 16, 0, 0);
+                } else {
+                    const int La = L - F::XSL;
+                    const int row = La / (AP / 4), q = La - row * (AP / 4);
+                    const int sidx = row / CT, c = row - sidx * CT;
+                    if (q < SBK / 4 && La < F::ASL)
+                        __builtin_amdgcn_global_load_lds((cg_gptr)cg_at<float>(wk, 4u * (unsigned)((sidx * a.Cout + c) * a.Cin + q * 4)), (cg_lptr)(st + p * 256), 16, 0, 0);
+                }
+            }
+        }
+    };
+
+    issue(0, 0, min(G::BT, a.T) * V, 0, tid0);
+    int after = 0;                                     // requests this wave made after the chunk's first stage (the previous copy-out's stores)
+    float st1 = 0.f, st2 = 0.f;
+    for (int t0 = 0; t0 < a.T; t0 += G::BT) {
+        const int bt = min(G::BT, a.T - t0);
+        const int ncols = bt * V;
+        const int nt0 = t0 + G::BT, nbt = nt0 < a.T ? min(G::BT, a.T - nt0) : 0;
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));                  // see above: nothing derived from it leaves this iteration
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int j = lane & 15, kq = lane >> 4;
+
+        // ---- x3 = W3 x + b3 for the 48 rows: column tiles as in x3_chunk (every SIMD five: wave w < 4 three, wave w + 4 two)
+        const int cw0 = 5 * (wave & 3) + (wave < 4 ? 0 : 3);
+        const bool third = wave < 4;
+        f32x4 acc[NRT][CW];
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+            for (int c = 0; c < CW; ++c) acc[rt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        int bcol[CW];
+#pragma unroll
+        for (int c = 0; c < CW; ++c) { const int col = (cw0 + c) * 16 + j; bcol[c] = (col < ncols && (c < 2 || third)) ? col : 0; }
+        for (int kc = 0; kc < nk; ++kc) {
+            cg_wait_vmcnt(kc == 0 ? after : 0);        // this wave's pieces of stage kc have landed (at kc = 0 the copy-out's stores may still be in flight)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // everyone's have; nobody reads the other stage any more
+            if (kc + 1 < nk) issue((kc + 1) & 1, t0, ncols, (kc + 1) * SBK, tid);
+            const float* As = X3 + (kc & 1) * F::STG + F::XSL * 4 + j * AP + kq;
+            const float* Bs = X3 + (kc & 1) * F::STG + kq * PB;
+#pragma unroll
+            for (int k4 = 0; k4 < SBK / 4; ++k4) {
+                float av[NRT], bv[CW];
+#pragma unroll
+                for (int rt = 0; rt < NRT; ++rt) av[rt] = As[rt * 16 * AP + k4 * 4];
+#pragma unroll
+                for (int c = 0; c < CW; ++c) bv[c] = Bs[k4 * 4 * PB + bcol[c]];
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int rt = 0; rt < NRT; ++rt) acc[rt][c] = mfma16(av[rt], bv[c], acc[rt][c]);
+                if (third) {
+#pragma unroll
+                    for (int rt = 0; rt < NRT; ++rt) acc[rt][2] = mfma16(av[rt], bv[2], acc[rt][2]);
+                }
+            }
+        }
+        float b3r[NRT][4];
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b3r[rt][r] = a.b3[rt * a.Cout + c0 + kq * 4 + r];       // row = rt*16 + kq*4 + r = (subset rt, channel kq*4 + r)
+        EFrag<G, ST> ef;
+        ef.ld(En, a.Cout, c0 + wave, tid);             // the first channel's E rows travel under the tile write
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // stages dead: the x3 tile may be written
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) {
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+                const int col = (cw0 + c) * 16 + j;
+                if (col >= ncols || (c == 2 && !third)) continue;
+                const int fr = col / V, v = col - fr * V;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) X3[((kq * 4 + r) * G::BT + fr) * (ST * V) + rt * V + v] = acc[rt][c][r] + b3r[rt][r];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        aggregate_mfma_g<G, ST, true>(En, a.Cout, c0, ef, X3, Zs, bt, tid);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+        // ---- copy-out: LDS -> registers, then (everybody done with the region) the next chunk's first stage, then the stores
+        const int c = tid / RL, lrow = tid % RL;
+        float4 zv[NV4], xv[ST][NV4];
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) {
+            const int p4 = lrow + i * RL;
+            zv[i] = p4 < (ncols >> 2) ? reinterpret_cast<const float4*>(Zs + c * G::NCOLS)[p4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (x3_out) {
+#pragma unroll
+            for (int s = 0; s < ST; ++s)
+#pragma unroll
+                for (int i = 0; i < NV4; ++i) {
+                    const int p4 = lrow + i * RL;
+                    const int fr = p4 / (V / 4), q = p4 - fr * (V / 4);
+                    xv[s][i] = p4 < (ncols >> 2) ? *reinterpret_cast<const float4*>(X3 + (c * G::BT + fr) * (ST * V) + s * V + 4 * q)
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+        }
+        if (nbt > 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            issue(0, nt0, nbt * V, 0, tid);
+            asm volatile("" ::: "memory");             // the stores below stay below: `after` counts them
+            after = nst;
+        }
+        const unsigned rowb = 4u * (unsigned)(c * a.T * V);
+        if (x3_out) {
+#pragma unroll
+            for (int s = 0; s < ST; ++s) {
+                float* xo = x3_out + (((long long)n * ST * a.Cout + s * a.Cout + c0) * a.T + t0) * V;
+#pragma unroll
+                for (int i = 0; i < NV4; ++i) {
+                    const int p4 = lrow + i * RL;
+                    if (p4 < (ncols >> 2)) *cg_at_w<float4>(xo, rowb + 16u * (unsigned)p4) = xv[s][i];
+                }
+            }
+        }
+        float* ybase = y + (((long long)n * a.Cout + c0) * a.T + t0) * V;
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) {
+            const int p4 = lrow + i * RL;
+            if (p4 < (ncols >> 2)) {
+                *cg_at_w<float4>(ybase, rowb + 16u * (unsigned)p4) = zv[i];
+                st1 += (zv[i].x + zv[i].y) + (zv[i].z + zv[i].w);
+                st2 = fmaf(zv[i].x, zv[i].x, fmaf(zv[i].y, zv[i].y, fmaf(zv[i].z, zv[i].z, fmaf(zv[i].w, zv[i].w, st2))));
+            }
+        }
+    }
+    if (stats_part) {
+#pragma unroll
+        for (int o = 1; o < RL; o <<= 1) { st1 += __shfl_xor(st1, o); st2 += __shfl_xor(st2, o); }
+        const int c = tid0 / RL;
+        if (tid0 % RL == 0) {
             stats_part[((long long)0 * a.Cout + c0 + c) * a.N + n] = st1;
             stats_part[((long long)1 * a.Cout + c0 + c) * a.N + n] = st2;
         }
@@ -706,6 +1034,7 @@ static int fill_args(const tamgcn_ctrgc_desc* d, CtrgcArgs* a, const char* who, 
     if ((long long)d->x.ctot * d->T * d->V >= (1LL << 31) || (long long)d->S * d->Cout * d->T * d->V >= (1LL << 31)) {
         tamgcn_set_error("%s: a sample block of >= 2^31 elements", who); return -1;
     }
+    if ((long long)d->T * d->V >= (1LL << 24)) { tamgcn_set_error("%s: T * V >= 2^24 (32-bit byte offsets inside a 32-row operand chunk)", who); return -1; }
     a->N = d->N; a->Cin = d->Cin; a->Cout = d->Cout; a->S = d->S; a->T = d->T;
     a->x = d->x.x1; a->x_ctot = d->x.ctot; a->x_coff = d->x.coff;
     a->w3 = d->w3; a->b3 = d->b3; a->E = d->E;
@@ -776,7 +1105,33 @@ extern "C" int tamgcn_ctrgc_fwd(const tamgcn_ctrgc_desc* d, float* y, float* sta
     CtrgcArgs a;
     const int ct = fwd_ct(d->Cout);
     if (fill_args(d, &a, "tamgcn_ctrgc_fwd", ct)) return -1;
-    if (ct == 16) {
+    // 16-channel tiles, S = 3: two workgroups per CU without a resident E tile (round 4).  Measured per layer shape (256 clips, us):
+    //   resident E (ctrgc_fwd_kernel<.., true>)    158 / 206 / 400 / 297 / 590 / 488   (l1 l2 l5 l6 l8 l9)
+    //   E from L2, register-staged operands        151 / 200 / 385 / 277 / 545 / 442
+    //   E from L2, LDS-DMA operands (fwd2)           - / 218 / 421 / 287 / 553 / 420
+    // TAMGCN_CTRGC_FWD2: 0 resident E everywhere, 1 (default) the faster of the other two by Cin, 2 fwd2 wherever it applies, 3 never fwd2.
+    static const int mode = [] { const char* e = getenv("TAMGCN_CTRGC_FWD2"); return e ? atoi(e) : 1; }();
+    const bool al16 = (((uintptr_t)d->x.x1 | (uintptr_t)d->w3) & 15) == 0;
+    const bool two = ct == 16 && d->S == 3 && mode != 0 && (d->Cin >= 64 || mode >= 2);   // the stem layer (Cin = 3) is faster with E resident inside the step (144 vs 173 us)
+    if (two && d->Cin % 16 == 0 && al16 && (mode == 2 || (mode == 1 && d->Cin >= 256))) {
+        static tg_devmask fw3g = 0;
+        constexpr size_t lds_ = Plan<G20W, 3>::LDS_NOE;
+        static_assert(lds_ <= 80 * 1024, "two workgroups per CU");
+        tg_allow_lds((const void*)ctrgc_fwd2_kernel<G20W, 3>, lds_, &fw3g);
+        hipLaunchKernelGGL((ctrgc_fwd2_kernel<G20W, 3>), dim3(grid_blocks(a)), dim3(G20W::NT), lds_, (hipStream_t)stream, a, y, stats_part, x3_out);
+        tamgcn_note_kernel("ctrgc_fwd2_kernel<Geo<%d, %d, %d, %d, %d>, 3>", G20W::V, G20W::CT, G20W::TB, G20W::NTQ, G20W::SBK);
+    } else if (two) {
+        static tg_devmask fw3e = 0;
+        constexpr size_t lds_ = Plan<G20W, 3>::LDS_NOE;
+        tg_allow_lds((const void*)ctrgc_fwd_kernel<G20W, 3, false>, lds_, &fw3e);
+        if (getenv("TAMGCN_DEBUG_OCC")) {
+            int nb_ = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_, (const void*)ctrgc_fwd_kernel<G20W, 3, false>, G20W::NT, lds_);
+            fprintf(stderr, "[tamgcn] ctrgc_fwd_kernel<CT 16, 3, E from L2>: %d workgroups per CU (%zu B LDS)\n", nb_, lds_);
+        }
+        hipLaunchKernelGGL((ctrgc_fwd_kernel<G20W, 3, false>), dim3(grid_blocks(a)), dim3(G20W::NT), lds_, (hipStream_t)stream, a, y, stats_part, x3_out);
+        tamgcn_note_kernel("ctrgc_fwd_kernel<Geo<%d, %d, %d, %d, %d>, 3, E from L2>", G20W::V, G20W::CT, G20W::TB, G20W::NTQ, G20W::SBK);
+    } else if (ct == 16) {
         if (d->S == 3) CTRGC_LAUNCH(ctrgc_fwd_kernel, G20W, 3, fw3, a, y, stats_part, x3_out);
         else CTRGC_LAUNCH(ctrgc_fwd_kernel, G20W, 1, fw1, a, y, stats_part, x3_out);
     } else {
