@@ -225,7 +225,7 @@ def test_bn_finalize_fwd_bwd():
 
 
 @pytest.mark.parametrize('shape', [(2, 3, 64, 9, 20, 3), (2, 64, 64, 20, 20, 3), (1, 128, 128, 5, 25, 3),
-                                   (2, 256, 256, 16, 20, 3), (2, 64, 32, 8, 20, 1)],
+                                   (2, 256, 256, 16, 20, 3), (2, 64, 32, 8, 20, 1), (2, 256, 64, 40, 20, 3), (3, 128, 48, 33, 20, 3)],
                          ids=lambda s: 'x'.join(map(str, s)))
 def test_ctrgc_fused_fwd_bwd(shape):
     """Fused CTRGC (S subsets summed) against the einsum formulation on the CPU."""
@@ -391,6 +391,23 @@ def test_pointwise_gemm_four_wave_layout():
     out = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-m', 'gpu', '-x', '-q', '-k',
                           'conv_fwd_bwd_wgrad or pointwise_dma or prologue_slices'], cwd=root,
                          env=dict(os.environ, TAMGCN_CONV_WAVES='4'), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
+
+
+@pytest.mark.parametrize('mode', ['0', '2', '3'])
+def test_ctrgc_forward_forms(mode):
+    """TAMGCN_CTRGC_FWD2 (read once per process) selects the form of the fused forward at 16-channel tiles: 0 = the E tile resident in
+    LDS (one workgroup per CU), 2 = ctrgc_fwd2_kernel wherever it applies (E fragments from L2, operands by LDS-DMA: frame chunks
+    16 + 16 + 8 at Cin = 256 and 16 + 4 at Cin = 64), 3 = E from L2 with register-staged operands everywhere; the default (1) picks
+    by Cin.  The fused-CTRGC test of this file in a child process per form."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get('TAMGCN_CTRGC_FWD2') is not None:
+        pytest.skip('already inside a child run')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-m', 'gpu', '-x', '-q', '-k', 'ctrgc_fused_fwd_bwd'],
+                         cwd=root, env=dict(os.environ, TAMGCN_CTRGC_FWD2=mode), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
 
 
