@@ -712,6 +712,8 @@ __device__ __forceinline__ void cg_wait_vmcnt(int n) {     // n is wave-uniform
     switch (n) {
         CG_VMCNT_CASE(0) CG_VMCNT_CASE(1) CG_VMCNT_CASE(2) CG_VMCNT_CASE(3) CG_VMCNT_CASE(4) CG_VMCNT_CASE(5) CG_VMCNT_CASE(6)
         CG_VMCNT_CASE(7) CG_VMCNT_CASE(8) CG_VMCNT_CASE(9) CG_VMCNT_CASE(10) CG_VMCNT_CASE(11) CG_VMCNT_CASE(12)
+        CG_VMCNT_CASE(13) CG_VMCNT_CASE(14) CG_VMCNT_CASE(15) CG_VMCNT_CASE(16) CG_VMCNT_CASE(17) CG_VMCNT_CASE(18)
+        CG_VMCNT_CASE(19) CG_VMCNT_CASE(20) CG_VMCNT_CASE(21) CG_VMCNT_CASE(22) CG_VMCNT_CASE(23) CG_VMCNT_CASE(24)
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 }
@@ -754,6 +756,7 @@ __global__ __launch_bounds__(G::NT, 4) void ctrgc_fwd2_kernel(const CtrgcArgs a,
     // one K chunk (16 input channels from k0) of the frames from t0 into stage `stage`: per lane a 16-byte slot of each of the
     // wave's pieces -- the image is linear in LDS, the layout sits in the source address
     auto issue = [&](int stage, int t0, int ncols, int k0, int tid) {
+        if (TG_CKO & 2) return;
         const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         float* st = X3 + stage * F::STG;
         const float* xk = xn + (long long)k0 * cs + (long long)t0 * V;
@@ -814,6 +817,7 @@ __global__ __launch_bounds__(G::NT, 4) void ctrgc_fwd2_kernel(const CtrgcArgs a,
                 for (int rt = 0; rt < NRT; ++rt) av[rt] = As[rt * 16 * AP + k4 * 4];
 #pragma unroll
                 for (int c = 0; c < CW; ++c) bv[c] = Bs[k4 * 4 * PB + bcol[c]];
+                if ((TG_CKO & 1) && k4) continue;
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll

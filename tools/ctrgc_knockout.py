@@ -6,7 +6,7 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 SIDE = os.path.join(ROOT, 'tools', '_side')
-MASKS = [1, 2, 4, 8, 16, 32, 64, 6, 70, 71, 48, 127]
+MASKS = [int(m) for m in os.environ.get('CKO_MASKS', '1,2,4,8,16,32,64,6,70,71,48,127').split(',')]
 if sys.argv[1] == 'build':
     from tam_gcn_amd import build as B
     B.build()
