@@ -728,11 +728,12 @@ struct Fwd2 {
     static constexpr int NPIECE = (XSL + ASL + 63) / 64, NPW = (NPIECE + G::NW - 1) / G::NW;
     static constexpr int STG = NPIECE * 256;                          // floats per stage: whole 1 KB pieces
     static_assert(P::NR == P::NRT * 16, "full weight row tiles");
-    static_assert(2 * STG <= P::REGION, "both stages inside the x3 tile's region");
+    static_assert(2 * STG <= P::REGION, "two stages inside the x3 tile's region");
+    static_assert(3 * STG <= P::REGION + G::CT * G::NCOLS, "a third stage may reach into the z tile (dead while the K loop runs)");
     static_assert(XSL % 64 == 0, "a piece holds x slots or weight slots, not both");
 };
 
-template <class G, int ST>
+template <class G, int ST, int NSTG>     // NSTG stages of 16 input channels: NSTG - 1 in flight while one is consumed
 __global__ __launch_bounds__(G::NT, 4) void ctrgc_fwd2_kernel(const CtrgcArgs a, float* y, float* stats_part, float* x3_out) {
     using P = Plan<G, ST>;
     using F = Fwd2<G, ST>;
@@ -741,8 +742,8 @@ __global__ __launch_bounds__(G::NT, 4) void ctrgc_fwd2_kernel(const CtrgcArgs a,
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int n, c0;
     if (!block_coords<G>(a, n, c0)) return;
-    float* X3 = smem;                                  // REGION floats: two GEMM stages, then the x3 tile [CT][BT][S*V]
-    float* Zs = X3 + P::REGION;                        // [CT][NCOLS]
+    float* X3 = smem;                                  // REGION floats: GEMM stages, then the x3 tile [CT][BT][S*V]
+    float* Zs = X3 + P::REGION;                        // [CT][NCOLS]; a third stage reaches into it -- only while the K loop runs, when nobody holds a z tile
     const int tid0 = threadIdx.x;
     const float* En = a.E + (long long)n * ST * a.Cout * G::VV;
     const int cs = a.T * V;                            // host: 64 * T * V < 2^32
@@ -755,8 +756,9 @@ __global__ __launch_bounds__(G::NT, 4) void ctrgc_fwd2_kernel(const CtrgcArgs a,
 
     // one K chunk (16 input channels from k0) of the frames from t0 into stage `stage`: per lane a 16-byte slot of each of the
     // wave's pieces -- the image is linear in LDS, the layout sits in the source address
-    auto issue = [&](int stage, int t0, int ncols, int k0, int tid) {
-        if (TG_CKO & 2) return;
+    auto issue = [&](int stage, int t0, int ncols, int k0, int tid) -> int {   // returns the number of requests this wave made (wave-uniform)
+        if (TG_CKO & 2) return 0;
+        int cnt = 0;
         const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         float* st = X3 + stage * F::STG;
         const float* xk = xn + (long long)k0 * cs + (long long)t0 * V;
@@ -768,20 +770,30 @@ __global__ __launch_bounds__(G::NT, 4) void ctrgc_fwd2_kernel(const CtrgcArgs a,
                 const int L = p * 64 + lane;
                 if (p * 64 < F::XSL) {
                     const int row = L / F::RS, c4 = L - row * F::RS;
-                    if (c4 * 4 < ncols)
-                        __builtin_amdgcn_global_load_lds((cg_gptr)cg_at<float>(xk, 4u * (unsigned)(row * cs + c4 * 4)), (cg_lptr)(st + p * 256), 16, 0, 0);
+                    const bool ok = c4 * 4 < ncols;
+                    if (__ballot(ok) != 0ull) {                              // the request exists or not for the whole wave: it is counted
+                        if (ok) __builtin_amdgcn_global_load_lds((cg_gptr)cg_at<float>(xk, 4u * (unsigned)(row * cs + c4 * 4)), (cg_lptr)(st + p * 256), 16, 0, 0);
+                        ++cnt;
+                    }
                 } else {
                     const int La = L - F::XSL;
                     const int row = La / (AP / 4), q = La - row * (AP / 4);
                     const int sidx = row / CT, c = row - sidx * CT;
-                    if (q < SBK / 4 && La < F::ASL)
-                        __builtin_amdgcn_global_load_lds((cg_gptr)cg_at<float>(wk, 4u * (unsigned)((sidx * a.Cout + c) * a.Cin + q * 4)), (cg_lptr)(st + p * 256), 16, 0, 0);
+                    const bool ok = q < SBK / 4 && La < F::ASL;
+                    if (__ballot(ok) != 0ull) {
+                        if (ok) __builtin_amdgcn_global_load_lds((cg_gptr)cg_at<float>(wk, 4u * (unsigned)((sidx * a.Cout + c) * a.Cin + q * 4)), (cg_lptr)(st + p * 256), 16, 0, 0);
+                        ++cnt;
+                    }
                 }
             }
         }
+        return cnt;
     };
 
-    issue(0, 0, min(G::BT, a.T) * V, 0, tid0);
+    int cnt = 0;                                       // requests per stage of the current frame chunk (this wave)
+#pragma unroll
+    for (int sg = 0; sg < NSTG - 1; ++sg)
+        if (sg < nk) cnt = issue(sg, 0, min(G::BT, a.T) * V, sg * SBK, tid0);
     int after = 0;                                     // requests this wave made after the chunk's first stage (the previous copy-out's stores)
     float st1 = 0.f, st2 = 0.f;
     for (int t0 = 0; t0 < a.T; t0 += G::BT) {
@@ -805,11 +817,14 @@ __global__ __launch_bounds__(G::NT, 4) void ctrgc_fwd2_kernel(const CtrgcArgs a,
 #pragma unroll
         for (int c = 0; c < CW; ++c) { const int col = (cw0 + c) * 16 + j; bcol[c] = (col < ncols && (c < 2 || third)) ? col : 0; }
         for (int kc = 0; kc < nk; ++kc) {
-            cg_wait_vmcnt(kc == 0 ? after : 0);        // this wave's pieces of stage kc have landed (at kc = 0 the copy-out's stores may still be in flight)
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // everyone's have; nobody reads the other stage any more
-            if (kc + 1 < nk) issue((kc + 1) & 1, t0, ncols, (kc + 1) * SBK, tid);
-            const float* As = X3 + (kc & 1) * F::STG + F::XSL * 4 + j * AP + kq;
-            const float* Bs = X3 + (kc & 1) * F::STG + kq * PB;
+            // this wave's pieces of stage kc have landed: the stages requested after it (and, for the stages requested before the
+            // copy-out's stores, those stores) may still be in flight
+            cg_wait_vmcnt((kc < NSTG - 1 ? after : 0) + (min(kc + NSTG - 2, nk - 1) - kc) * cnt);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // everyone's have; nobody reads stage kc - 1 any more
+            if (kc + NSTG - 1 < nk) issue((kc + NSTG - 1) % NSTG, t0, ncols, (kc + NSTG - 1) * SBK, tid);
+            const int slot = kc % NSTG;
+            const float* As = X3 + slot * F::STG + F::XSL * 4 + j * AP + kq;
+            const float* Bs = X3 + slot * F::STG + kq * PB;
 #pragma unroll
             for (int k4 = 0; k4 < SBK / 4; ++k4) {
                 float av[NRT], bv[CW];
@@ -872,7 +887,9 @@ __global__ __launch_bounds__(G::NT, 4) void ctrgc_fwd2_kernel(const CtrgcArgs a,
         }
         if (nbt > 0) {
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            issue(0, nt0, nbt * V, 0, tid);
+#pragma unroll
+            for (int sg = 0; sg < NSTG - 1; ++sg)      // slots 0 .. NSTG - 2, as the next K loop expects them (the z tile is dead too: barrier above)
+                if (sg < nk) cnt = issue(sg, nt0, nbt * V, sg * SBK, tid);
             asm volatile("" ::: "memory");             // the stores below stay below: `after` counts them
             after = nst;
         }
@@ -1121,8 +1138,11 @@ extern "C" int tamgcn_ctrgc_fwd(const tamgcn_ctrgc_desc* d, float* y, float* sta
         static tg_devmask fw3g = 0;
         constexpr size_t lds_ = Plan<G20W, 3>::LDS_NOE;
         static_assert(lds_ <= 80 * 1024, "two workgroups per CU");
-        tg_allow_lds((const void*)ctrgc_fwd2_kernel<G20W, 3>, lds_, &fw3g);
-        hipLaunchKernelGGL((ctrgc_fwd2_kernel<G20W, 3>), dim3(grid_blocks(a)), dim3(G20W::NT), lds_, (hipStream_t)stream, a, y, stats_part, x3_out);
+        // two stages: a third one (it fits, reaching into the z tile while the K loop runs) was measured SLOWER at every shape --
+        // 231 / 450 / 316 / 607 / 487 us against 223 / 422 / 292 / 564 / 440 (l2 l5 l6 l8 l9, same box): more requests in flight
+        // load the L2 -> LDS path further, they do not hide its latency
+        tg_allow_lds((const void*)ctrgc_fwd2_kernel<G20W, 3, 2>, lds_, &fw3g);
+        hipLaunchKernelGGL((ctrgc_fwd2_kernel<G20W, 3, 2>), dim3(grid_blocks(a)), dim3(G20W::NT), lds_, (hipStream_t)stream, a, y, stats_part, x3_out);
         tamgcn_note_kernel("ctrgc_fwd2_kernel<Geo<%d, %d, %d, %d, %d>, 3>", G20W::V, G20W::CT, G20W::TB, G20W::NTQ, G20W::SBK);
     } else if (two) {
         static tg_devmask fw3e = 0;
