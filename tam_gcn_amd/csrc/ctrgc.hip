@@ -25,6 +25,9 @@
 // shape: two workgroups of four waves put the same two waves on a SIMD as one workgroup of eight, and the phases that
 // bound the kernel -- waiting for the staged operands and for the copy-out stores to drain (vmcnt retires in order) --
 // do not overlap better for it.  dx3 (no GEMM, no staging): CT = 8, two workgroups per CU.
+// Round 4 added two forms of the 16-channel forward WITHOUT the resident E tile (80 KB of LDS, two workgroups per CU, 128 registers
+// per wave): ctrgc_fwd_kernel<G, ST, false> (this kernel with the aggregation's E fragments read from global memory) and
+// ctrgc_fwd2_kernel (its operands by LDS-DMA as well); tamgcn_ctrgc_fwd picks by Cin -- see the comment above ctrgc_fwd2_kernel.
 //
 // ctrgc_bwd_dx3_kernel:  dx3_s[c,t,v] = sum_u E_s[c,u,v] dy[c,t,u], on the matrix cores from the same E layout.
 //
